@@ -1,0 +1,205 @@
+/*
+ * rnd.h — C ABI of the MI355X-native frame hot path (vertex transform -> triangle
+ * setup + tile binning -> per-tile raster with depth -> deferred material/light shading).
+ *
+ * This is the drop-in boundary for the reference's `VisualServer`
+ * (reference: src/renderer/visual_server.rs:54-874).  The reference has no FFI of its
+ * own; the seam sits where `Pipeline3d::render` + `Backend` talk to wgpu
+ * (src/renderer/pipeline3d.rs:261-368, src/renderer/backend.rs:455-498).  Every entry
+ * point below cites the reference method it replaces.  A Rust `extern "C"` block that
+ * binds these 1:1 is in integration/rust/rnd-sys.
+ *
+ * Conventions
+ *  - every function returns RND_OK (0) or a negative rnd_status; rnd_last_error() gives text.
+ *  - matrices are column-major f32[16] exactly as glam `Mat4::to_cols_array()`
+ *    (visual_server.rs:212-214, :491).  Affine transforms are passed as Mat4 with last
+ *    row (0,0,0,1).
+ *  - the library copies everything it is given (as the reference does at
+ *    backend.rs:257-276); the caller keeps ownership of its buffers.
+ *  - one context is single-threaded (`&mut self` in the reference); contexts on different
+ *    devices are independent.
+ *  - plain pointers and sizes only; no torch / C++ types cross this boundary.
+ */
+#ifndef RND_H
+#define RND_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rnd_ctx rnd_ctx;
+
+typedef enum rnd_status {
+    RND_OK = 0,
+    RND_ERR_INVALID = -1,      /* bad argument (null pointer, size 0, index out of range) */
+    RND_ERR_UNKNOWN_ID = -2,   /* mesh / material id not registered (reference: unwrap() panic) */
+    RND_ERR_DEVICE = -3,       /* HIP error; maps to wgpu::SurfaceError::Lost on the Rust side */
+    RND_ERR_OOM = -4,          /* allocation failed; maps to wgpu::SurfaceError::OutOfMemory */
+    RND_ERR_UNSUPPORTED = -5,  /* setting exists in the reference but is not built yet */
+    RND_ERR_NO_FRAME = -6      /* read-back before the first rnd_render */
+} rnd_status;
+
+#define RND_NONE 0xFFFFFFFFu
+
+/* reference: src/renderer/vertex.rs:3-9 — #[repr(C)] 32-byte AoS vertex */
+typedef struct rnd_vertex {
+    float position[3];
+    float normal[3];
+    float uv[2];
+} rnd_vertex;
+
+/* reference: src/mesh.rs:9-13 `Submesh{vertices,indices,material}`; u32 TriangleList
+ * indices (pipeline3d.rs:341).  material_id == RND_NONE selects the default material
+ * (visual_server.rs:672-677). */
+typedef struct rnd_submesh_desc {
+    const rnd_vertex* vertices;
+    uint32_t n_vertices;
+    const uint32_t* indices;
+    uint32_t n_indices;      /* multiple of 3 */
+    uint32_t material_id;
+} rnd_submesh_desc;
+
+/* reference: enum ToneMapping, visual_server.rs:1218-1223 */
+enum { RND_TONE_MAPPING_NONE = 0, RND_TONE_MAPPING_REINHARD = 1 };
+/* reference: LightKind::id(), src/light.rs:52-59 */
+enum { RND_LIGHT_DIRECTIONAL = 0, RND_LIGHT_POINT = 1 };
+/* reference: BillboardMode, src/material.rs:21-25 / visual_server.rs:716-720 */
+enum { RND_BILLBOARD_OFF = 0, RND_BILLBOARD_ON = 1, RND_BILLBOARD_FIXED_SIZE = 2 };
+
+/* Per-frame kernel timings (HIP events on the context's stream), milliseconds. */
+typedef struct rnd_timings {
+    float transform_ms;   /* K1 vertex transform */
+    float setup_ms;       /* K2a triangle setup + cull + clip + tile count */
+    float scan_ms;        /* tile offset scan */
+    float bin_ms;         /* K2b bin fill */
+    float raster_ms;      /* K3 per-tile raster */
+    float shade_ms;       /* K4 deferred shade + tone map */
+    float frame_ms;       /* first kernel start -> last kernel end */
+    float shadow_ms;      /* shadow-cascade depth passes (directional lights) */
+} rnd_timings;
+
+/* Per-frame counters used to state algorithmic bytes. */
+typedef struct rnd_frame_stats {
+    uint64_t n_vertices;      /* Nv: vertices transformed this frame (sum over draw items) */
+    uint64_t n_triangles;     /* Nt: input triangles this frame */
+    uint64_t n_setup;         /* Nt_vis: setup records written (after cull/clip) */
+    uint64_t n_bin_entries;   /* Nbin: (record, tile) pairs */
+    uint64_t n_pixels;        /* P: pixels this context rasterizes (owned tiles only) */
+    uint32_t n_draw_items;    /* M */
+    uint32_t n_lights;        /* L */
+    uint32_t n_tiles;         /* tiles owned by this context */
+    uint32_t overflow;        /* 1 if an internal buffer had to grow and the frame was re-run */
+} rnd_frame_stats;
+
+/* ---- lifecycle -------------------------------------------------------------------- */
+
+/* reference: VisualServer::new (visual_server.rs:55-154).  No window: width/height are the
+ * surface size; `device` is the HIP device ordinal.  Defaults as the reference: render size
+ * factor 1.0, MSAA 1, tone mapping Reinhard (:85-90), ambient (0.3,0.5,0.9,0.04) (:67),
+ * default material white/lit (material.rs:10-19), unit quad mesh (:865-873). */
+int rnd_create(rnd_ctx** out, uint32_t width, uint32_t height, int device);
+void rnd_destroy(rnd_ctx* ctx);
+/* text of the last error on this context (or of the last failed rnd_create when ctx==NULL) */
+const char* rnd_last_error(const rnd_ctx* ctx);
+/* "hip-gfx950" for the product library, "cpu-oracle" for the checker in oracle/ */
+const char* rnd_backend_name(void);
+
+/* ---- settings (reference: visual_server.rs:156-190) -------------------------------- */
+int rnd_render_size(const rnd_ctx* ctx, uint32_t* width, uint32_t* height);  /* :156 */
+int rnd_set_render_size(rnd_ctx* ctx, uint32_t width, uint32_t height);      /* :160 */
+int rnd_render_size_factor(const rnd_ctx* ctx, float* factor);               /* :165 */
+int rnd_set_render_size_factor(rnd_ctx* ctx, float factor);                  /* :169 */
+int rnd_msaa_sample_count(const rnd_ctx* ctx, uint32_t* count);              /* :174 */
+int rnd_set_msaa(rnd_ctx* ctx, uint32_t sample_count);                       /* :178 */
+int rnd_tone_mapping(const rnd_ctx* ctx, uint32_t* mode);                    /* :183 */
+int rnd_set_tone_mapping(rnd_ctx* ctx, uint32_t mode);                       /* :187 */
+
+/* ---- resources (reference: register_mesh :664-695, register_material :697-750) ----- */
+/* Replaces the AssetServer lookup + create_vertex_buffer/create_index_buffer upload.
+ * Registering an id twice replaces the mesh. */
+int rnd_register_mesh(rnd_ctx* ctx, uint32_t mesh_id, uint32_t n_submeshes,
+                      const rnd_submesh_desc* submeshes);
+/* reference: update_render_material_data :710-750 packs MaterialUniform :978-985.
+ * texture_id RND_NONE = the 1x1 white texture (:736). */
+int rnd_register_material(rnd_ctx* ctx, uint32_t material_id, const float base_color[4],
+                          uint32_t billboard_mode, uint32_t unlit, uint32_t texture_id);
+/* reference: register_texture/update_texture :752-769; data layout = Image::data(),
+ * tightly packed RGBA8 mip levels (crates/asset_image/src/image.rs:99-113). */
+int rnd_register_texture(rnd_ctx* ctx, uint32_t texture_id, uint32_t width, uint32_t height,
+                         uint32_t mip_levels, const uint8_t* rgba8_mipchain);
+
+/* ---- per-frame state --------------------------------------------------------------- */
+/* reference: set_camera(&Affine3A, &Camera) :206-222; Camera{vfov,aspect_ratio,near,far}
+ * src/camera.rs:4-9; projection = perspective_lh (camera.rs:27-29); view = inverse(transform). */
+int rnd_set_camera(rnd_ctx* ctx, const float transform_cols[16], float vfov, float aspect_ratio,
+                   float z_near, float z_far);
+/* reference: set_light(UniqueNodeId, Affine3A, &Light) :350-474; color.a is the intensity;
+ * radius is ignored for directional lights (Light::radius().unwrap_or_default()). */
+int rnd_set_light(rnd_ctx* ctx, uint64_t id, const float transform_cols[16], const float color[4],
+                  uint32_t kind, float radius);
+/* reference: set_mesh_instance(UniqueNodeId, Affine3A, Handle<Mesh>, &AssetServer) :481-506
+ * (material_override None, casts_shadows true). */
+int rnd_set_mesh_instance(rnd_ctx* ctx, uint64_t id, const float transform_cols[16],
+                          uint32_t mesh_id);
+/* Same, exposing RenderMeshInstance{material_override, casts_shadows} (:955-962), which the
+ * reference only sets through set_sprite (:539-548). */
+int rnd_set_mesh_instance_ex(rnd_ctx* ctx, uint64_t id, const float transform_cols[16],
+                             uint32_t mesh_id, uint32_t material_override, uint32_t casts_shadows);
+/* reference: set_sprite(id, Affine3A, Handle<Image>, Color, ..) :508-550 — unit quad, billboard
+ * On, unlit, no shadows, base colour = `color`, texture = texture_id (RND_NONE = white). */
+int rnd_set_sprite(rnd_ctx* ctx, uint64_t id, const float transform_cols[16], uint32_t texture_id,
+                   const float color[4]);
+/* reference: reset_scene :579-581 — drops meshes, materials, textures, lights, instances. */
+int rnd_reset_scene(rnd_ctx* ctx);
+
+/* ---- frame ------------------------------------------------------------------------- */
+/* reference: VisualServer::render :224-311 (+ Pipeline3d::render, Backend::render).
+ * Enqueues the whole frame on the context's stream and returns; rnd_finish waits for it. */
+int rnd_render(rnd_ctx* ctx);
+int rnd_finish(rnd_ctx* ctx);
+
+/* ---- read-backs (what the reference shows on the surface / in its H/J/K debug views) -- */
+/* final 8-bit sRGB surface image, row-major, origin top-left, width*height*4 bytes */
+int rnd_read_color_rgba8(rnd_ctx* ctx, uint8_t* dst);
+/* linear HDR colour of the Rgba16Float target widened to f32, width*height*3 floats */
+int rnd_read_color_hdr(rnd_ctx* ctx, float* dst);
+/* Depth32Float target, width*height floats (clear value 1.0) */
+int rnd_read_depth(rnd_ctx* ctx, float* dst);
+/* coverage mask: 1 where a fragment won the depth test, width*height bytes */
+int rnd_read_coverage(rnd_ctx* ctx, uint8_t* dst);
+/* id (draw order) of the winning triangle per pixel, RND_NONE where uncovered */
+int rnd_read_triangle_ids(rnd_ctx* ctx, uint32_t* dst);
+int rnd_last_timings(rnd_ctx* ctx, rnd_timings* out);
+int rnd_frame_stats_get(rnd_ctx* ctx, rnd_frame_stats* out);
+
+/* ---- multi-GPU (no counterpart in the reference, which is single-device;
+ *      north_star: sort-first by screen tiles, sort-last depth composite) ------------- */
+/* Sort-first: this context rasterizes/shades only the screen tiles it owns.  Ownership is
+ * interleaved in blocks of `group` x `group` tiles: owner = (gx + gy * stride) mod world. */
+int rnd_set_tile_partition(rnd_ctx* ctx, uint32_t rank, uint32_t world);
+/* tile edge in pixels (square tiles) and the number of tiles this context owns */
+int rnd_tile_info(const rnd_ctx* ctx, uint32_t* tile_px, uint32_t* n_owned_tiles,
+                  uint32_t* n_tiles_total);
+/* Device pointer (on this context's device) of the tile-major RGBA8 output of the last frame:
+ * n_owned_tiles * tile_px*tile_px*4 bytes, tiles in ascending tile index.  This is what a
+ * rank hands to the RCCL gather. */
+int rnd_tiles_device_ptr(rnd_ctx* ctx, void** dev_ptr, uint64_t* n_bytes);
+/* On the gathering rank: scatter `src_rank`'s tile-major buffer (device pointer on this
+ * context's device) into this context's row-major RGBA8 frame. */
+int rnd_detile(rnd_ctx* ctx, uint32_t src_rank, uint32_t world, const void* dev_tiles);
+/* Sort-last: device pointer of the packed (depth bits << 32 | rgba8) u64 frame, width*height
+ * entries, row-major; min-reducing these across ranks is the depth composite. */
+int rnd_packed_device_ptr(rnd_ctx* ctx, void** dev_ptr, uint64_t* n_bytes);
+/* Unpack a (reduced) packed frame on this context's device into its RGBA8 + depth frame. */
+int rnd_unpack(rnd_ctx* ctx, const void* dev_packed);
+/* Use the caller's HIP stream (hipStream_t as void*) for all work of this context; NULL = own stream. */
+int rnd_set_stream(rnd_ctx* ctx, void* hip_stream);
+/* Device pointer of the row-major RGBA8 frame (for callers that keep the image on the GPU). */
+int rnd_color_device_ptr(rnd_ctx* ctx, void** dev_ptr, uint64_t* n_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RND_H */

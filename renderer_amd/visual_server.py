@@ -1,0 +1,254 @@
+"""Python host-side mirror of the reference's `VisualServer` over the C ABI (include/rnd.h).
+
+reference: src/renderer/visual_server.rs:54-874.  Method names, argument meaning and error
+behaviour follow the reference; the wgpu plumbing behind them is replaced by the HIP library.
+Failures the reference turns into panics (`unwrap()` on an unknown handle) raise RndError.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import RND_NONE, FrameStats, RndError, SubmeshDesc, Timings
+from .types import (AssetServer, Camera, Color, Handle, Light, Material, Mesh, to_cols_array)
+
+
+class ToneMapping:
+    """visual_server.rs:1218-1223"""
+    Off = 0      # `None` in the reference
+    Reinhard = 1
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class VisualServer:
+    def __init__(self, width, height, asset_server=None, device=0, capi=None):
+        """reference: VisualServer::new(window, asset_server) visual_server.rs:55-154"""
+        self.api = capi if capi is not None else _capi.load_product()
+        self.asset_server = asset_server if asset_server is not None else AssetServer()
+        self._ctx = C.c_void_p()
+        rc = self.api.create(C.byref(self._ctx), int(width), int(height), int(device))
+        if rc != 0:
+            raise RndError(rc, (self.api.last_error(None) or b"").decode())
+        self._mesh_ids = {}        # Handle<Mesh> -> mesh id      (RenderScene.meshes)
+        self._material_ids = {}    # Handle<Material> -> id       (RenderScene.materials)
+        self._texture_ids = {}     # Handle<Image> -> id          (RenderScene.textures)
+        self._next_id = 1
+
+    # -- plumbing ---------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            raise RndError(rc, (self.api.last_error(self._ctx) or b"").decode())
+
+    def close(self):
+        if self._ctx:
+            self.api.destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def backend_name(self):
+        return self.api.backend_name().decode()
+
+    # -- settings (visual_server.rs:156-190) --------------------------------------------
+    def render_size(self):
+        w, h = C.c_uint32(), C.c_uint32()
+        self._check(self.api.render_size(self._ctx, C.byref(w), C.byref(h)))
+        return (w.value, h.value)
+
+    def set_render_size(self, size):
+        self._check(self.api.set_render_size(self._ctx, int(size[0]), int(size[1])))
+
+    def render_size_factor(self):
+        f = C.c_float()
+        self._check(self.api.render_size_factor(self._ctx, C.byref(f)))
+        return f.value
+
+    def set_render_size_factor(self, factor):
+        self._check(self.api.set_render_size_factor(self._ctx, float(factor)))
+
+    def msaa_sample_count(self):
+        n = C.c_uint32()
+        self._check(self.api.msaa_sample_count(self._ctx, C.byref(n)))
+        return n.value
+
+    def set_msaa(self, sample_count):
+        self._check(self.api.set_msaa(self._ctx, int(sample_count)))
+
+    def tone_mapping(self):
+        m = C.c_uint32()
+        self._check(self.api.tone_mapping(self._ctx, C.byref(m)))
+        return m.value
+
+    def set_tone_mapping(self, tone_mapping):
+        self._check(self.api.set_tone_mapping(self._ctx, int(tone_mapping)))
+
+    # -- registration (visual_server.rs:664-769) ---------------------------------------
+    def _register_material(self, handle):
+        if handle is None:
+            return RND_NONE
+        if handle in self._material_ids:
+            return self._material_ids[handle]
+        material = self.asset_server.get(handle)
+        tex = RND_NONE
+        if material.base_color_image is not None:
+            tex = self._register_texture(material.base_color_image)
+        mid = self._next_id
+        self._next_id += 1
+        base = np.asarray(material.base_color.to_array(), dtype=np.float32)
+        self._check(self.api.register_material(self._ctx, mid, _fp(base), int(material.billboard_mode),
+                                               int(bool(material.unlit)), tex))
+        self._material_ids[handle] = mid
+        return mid
+
+    def _register_texture(self, handle):
+        if handle in self._texture_ids:
+            return self._texture_ids[handle]
+        image = self.asset_server.get(handle)
+        tid = self._next_id
+        self._next_id += 1
+        data = np.ascontiguousarray(image.data, dtype=np.uint8)
+        self._check(self.api.register_texture(self._ctx, tid, int(image.width), int(image.height),
+                                              int(image.mip_level_count), data.ctypes.data))
+        self._texture_ids[handle] = tid
+        return tid
+
+    def register_mesh(self, handle):
+        if handle in self._mesh_ids:
+            return self._mesh_ids[handle]
+        mesh = self.asset_server.get(handle)
+        descs = (SubmeshDesc * len(mesh.submeshes))()
+        keep = []
+        for d, s in zip(descs, mesh.submeshes):
+            keep.append((s.vertices, s.indices))
+            d.vertices = s.vertices.ctypes.data
+            d.n_vertices = len(s.vertices)
+            d.indices = s.indices.ctypes.data
+            d.n_indices = len(s.indices)
+            d.material_id = self._register_material(s.material)
+        mid = self._next_id
+        self._next_id += 1
+        self._check(self.api.register_mesh(self._ctx, mid, len(mesh.submeshes), descs))
+        self._mesh_ids[handle] = mid
+        return mid
+
+    # -- per-frame state ---------------------------------------------------------------
+    def set_camera(self, transform, camera: Camera):
+        """visual_server.rs:206-222"""
+        t = to_cols_array(transform)
+        self._check(self.api.set_camera(self._ctx, _fp(t), camera.vfov, camera.aspect_ratio,
+                                        camera.near, camera.far))
+
+    def set_light(self, id, transform, light: Light):
+        """visual_server.rs:350-356"""
+        t = to_cols_array(transform)
+        col = np.asarray(light.color.to_array(), dtype=np.float32)
+        self._check(self.api.set_light(self._ctx, int(id), _fp(t), _fp(col), light.kind_id(),
+                                       float(light.radius() or 0.0)))
+
+    def set_mesh_instance(self, id, transform, mesh_handle: Handle, asset_server=None):
+        """visual_server.rs:481-506"""
+        if asset_server is not None:
+            self.asset_server = asset_server
+        mid = self.register_mesh(mesh_handle)
+        t = to_cols_array(transform)
+        self._check(self.api.set_mesh_instance(self._ctx, int(id), _fp(t), mid))
+
+    def set_sprite(self, id, transform, image_handle, base_color: Color, asset_server=None):
+        """visual_server.rs:508-550"""
+        if asset_server is not None:
+            self.asset_server = asset_server
+        tex = RND_NONE if image_handle is None else self._register_texture(image_handle)
+        t = to_cols_array(transform)
+        col = np.asarray(base_color.to_array(), dtype=np.float32)
+        self._check(self.api.set_sprite(self._ctx, int(id), _fp(t), tex, _fp(col)))
+
+    def reset_scene(self):
+        """visual_server.rs:579-581"""
+        self._check(self.api.reset_scene(self._ctx))
+        self._mesh_ids.clear()
+        self._material_ids.clear()
+        self._texture_ids.clear()
+
+    # -- frame ---------------------------------------------------------------------------
+    def render(self):
+        """visual_server.rs:224-311 — enqueues the frame; read-backs wait for it."""
+        self._check(self.api.render(self._ctx))
+
+    def finish(self):
+        self._check(self.api.finish(self._ctx))
+
+    # -- read-backs ----------------------------------------------------------------------
+    def _read(self, fn, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        self._check(fn(self._ctx, out.ctypes.data))
+        return out
+
+    def read_color_rgba8(self):
+        w, h = self.render_size()
+        return self._read(self.api.read_color_rgba8, (h, w, 4), np.uint8)
+
+    def read_color_hdr(self):
+        w, h = self.render_size()
+        return self._read(self.api.read_color_hdr, (h, w, 3), np.float32)
+
+    def read_depth(self):
+        w, h = self.render_size()
+        return self._read(self.api.read_depth, (h, w), np.float32)
+
+    def read_coverage(self):
+        w, h = self.render_size()
+        return self._read(self.api.read_coverage, (h, w), np.uint8)
+
+    def read_triangle_ids(self):
+        w, h = self.render_size()
+        return self._read(self.api.read_triangle_ids, (h, w), np.uint32)
+
+    def last_timings(self):
+        t = Timings()
+        self._check(self.api.last_timings(self._ctx, C.byref(t)))
+        return t.as_dict()
+
+    def frame_stats(self):
+        s = FrameStats()
+        self._check(self.api.frame_stats_get(self._ctx, C.byref(s)))
+        return s.as_dict()
+
+    # -- multi-GPU -----------------------------------------------------------------------
+    def set_tile_partition(self, rank, world):
+        self._check(self.api.set_tile_partition(self._ctx, int(rank), int(world)))
+
+    def tile_info(self):
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._check(self.api.tile_info(self._ctx, C.byref(a), C.byref(b), C.byref(c)))
+        return {"tile_px": a.value, "n_owned": b.value, "n_total": c.value}
+
+    def _devptr(self, fn):
+        p, n = C.c_void_p(), C.c_uint64()
+        self._check(fn(self._ctx, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def tiles_device_ptr(self):
+        return self._devptr(self.api.tiles_device_ptr)
+
+    def packed_device_ptr(self):
+        return self._devptr(self.api.packed_device_ptr)
+
+    def color_device_ptr(self):
+        return self._devptr(self.api.color_device_ptr)
+
+    def detile(self, src_rank, world, dev_ptr):
+        self._check(self.api.detile(self._ctx, int(src_rank), int(world), C.c_void_p(dev_ptr)))
+
+    def unpack(self, dev_ptr):
+        self._check(self.api.unpack(self._ctx, C.c_void_p(dev_ptr)))
+
+    def set_stream(self, hip_stream):
+        self._check(self.api.set_stream(self._ctx, C.c_void_p(hip_stream)))

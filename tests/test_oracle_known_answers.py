@@ -1,0 +1,353 @@
+"""Known-answer tests that pin the CPU oracle.
+
+The reference holds no tests or golden vectors for this path ("parity unpinned"), so every
+expected value here is derived by hand from the WGSL text (render_mesh.wgsl, show_texture.wgsl)
+and the WebGPU rasterization rules; the derivation is in each test.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from renderer_amd.types import (AssetServer, Camera, Color, Light, Material, Mesh, Submesh, from_rotation_y,
+                                from_translation, identity)
+from tests.helpers import make_vertices, oracle_server, screen_to_view, tri_mesh
+
+W, H = 64, 48
+
+
+def srgb8(x):
+    x = min(max(x, 0.0), 1.0)
+    y = 12.92 * x if x <= 0.0031308 else 1.055 * x ** (1 / 2.4) - 0.055
+    return int(y * 255.0 + 0.5)
+
+
+def reinhard(c):
+    lum = 0.2126 * c[0] + 0.7152 * c[1] + 0.0722 * c[2]
+    return [v / (lum + 1.0) for v in c]
+
+
+def server(mode="deferred", w=W, h=H):
+    vs = oracle_server(w, h, mode=mode, threads=1)
+    cam = Camera(aspect_ratio=w / h)
+    vs.set_camera(identity(), cam)
+    return vs, cam
+
+
+def screen_tri(vs, cam, pts, z=2.0, node=1, w=W, h=H, material=None):
+    """Add a triangle whose vertices project exactly onto framebuffer positions pts (px, py)."""
+    pos = [screen_to_view(px, py, z if np.isscalar(z) else z[k], w, h, cam) for k, (px, py) in enumerate(pts)]
+    mesh = vs.asset_server.add(tri_mesh(pos, material=material))
+    vs.set_mesh_instance(node, identity(), mesh)
+    return pos
+
+
+# ---- KA1: projection / depth --------------------------------------------------------------
+
+def test_ka1_depth_of_perspective_lh():
+    # depth = r*(z-near)/z with r = far/(far-near); default camera near .05 far 100
+    vs, cam = server()
+    for z_view, node in ((1.0, 1),):
+        screen_tri(vs, cam, [(0, 0), (0, H), (W, 0)], z=z_view, node=node)   # CCW with y up
+    vs.render()
+    d = vs.read_depth()
+    r = 100.0 / 99.95
+    assert vs.read_coverage()[5, 5] == 1
+    assert abs(float(d[5, 5]) - r * 0.95) < 2e-7
+    assert abs(float(d[5, 5]) - 0.9504752) < 1e-6
+
+
+def test_ka1_near_and_far_planes():
+    api_vs, cam = server()
+    m = np.zeros(16, dtype=np.float32)
+    import ctypes as C
+    P, V, PV = (np.zeros(16, np.float32) for _ in range(3))
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    api_vs.api.get_matrices(api_vs._ctx, fp(P), fp(V), fp(PV))
+    P = P.reshape(4, 4).T
+    for z, want in ((0.05, 0.0), (100.0, 1.0)):
+        clip = P @ np.array([0, 0, z, 1], dtype=np.float32)
+        assert abs(clip[2] / clip[3] - want) < 1e-6
+    # glam perspective_lh layout: w = h/aspect, h = 1/tan(fov/2), m[2][3] = 1, m[3][2] = -r*near
+    h = 1.0 / math.tan(0.65)
+    assert abs(P[1, 1] - h) < 1e-6 and abs(P[0, 0] - h / cam.aspect_ratio) < 1e-6
+    assert P[3, 2] == 1.0 and abs(P[2, 3] + (100 / 99.95) * 0.05) < 1e-7
+
+
+# ---- KA2: coverage, top-left rule ----------------------------------------------------------
+
+def test_ka2_top_left_rule_on_pixel_centres():
+    # Right triangle with vertices on pixel CENTRES (10.5,10.5) (10.5,20.5) (20.5,10.5): the
+    # vertical edge x=10.5 is a left edge (in), the horizontal edge y=10.5 is a top edge (in), the
+    # hypotenuse x+y=31 is neither (pixels with centre exactly on it are out).
+    vs, cam = server()
+    screen_tri(vs, cam, [(10.5, 10.5), (10.5, 20.5), (20.5, 10.5)])
+    vs.render()
+    cov = vs.read_coverage()
+    ys, xs = np.nonzero(cov)
+    assert xs.min() == 10 and ys.min() == 10          # left column and top row are covered
+    for j in range(H):
+        for i in range(W):
+            inside = i >= 10 and j >= 10 and (i + j) < 30    # centre (i+.5)+(j+.5) < 31
+            assert cov[j, i] == int(inside), (i, j)
+
+
+def test_ka2_bottom_right_edges_excluded():
+    # Mirror image: vertices (20.5,20.5) (20.5,10.5) (10.5,20.5); the vertical edge x=20.5 is a
+    # right edge and the horizontal edge y=20.5 a bottom edge: both excluded.  The hypotenuse
+    # x+y=31 now has the interior on its right, so it is a LEFT edge: centres on it are covered.
+    vs, cam = server()
+    screen_tri(vs, cam, [(20.5, 20.5), (20.5, 10.5), (10.5, 20.5)])
+    vs.render()
+    cov = vs.read_coverage()
+    for j in range(H):
+        for i in range(W):
+            inside = i < 20 and j < 20 and (i + j) >= 30    # (i+.5)+(j+.5) >= 31
+            assert cov[j, i] == int(inside), (i, j)
+
+
+def test_ka2_shared_edge_covers_each_pixel_once():
+    rng = np.random.default_rng(3)
+    for trial in range(20):
+        vs, cam = server()
+        p = rng.uniform(4, 44, size=(4, 2))
+        # quad a-b-c-d split along a-c; order the two triangles CCW with y up (= clockwise in fb)
+        a, b, c, d = p
+        def ccw_up(t):
+            (x0, y0), (x1, y1), (x2, y2) = t
+            area_fb = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0)
+            return t if area_fb < 0 else [t[0], t[2], t[1]]
+        t1, t2 = ccw_up([a, b, c]), ccw_up([a, c, d])
+        # only use configurations where b and d are on opposite sides of a-c
+        s1 = float((c - a)[0] * (b - a)[1] - (c - a)[1] * (b - a)[0])
+        s2 = float((c - a)[0] * (d - a)[1] - (c - a)[1] * (d - a)[0])
+        if s1 * s2 >= 0:
+            continue
+        screen_tri(vs, cam, t1, node=1)
+        vs.render()
+        c1 = vs.read_coverage().astype(int)
+        vs.reset_scene()
+        screen_tri(vs, cam, t2, node=2)
+        vs.render()
+        c2 = vs.read_coverage().astype(int)
+        vs.reset_scene()
+        screen_tri(vs, cam, t1, node=1)
+        screen_tri(vs, cam, t2, node=2)
+        vs.render()
+        cu = vs.read_coverage().astype(int)
+        assert (c1 & c2).sum() == 0
+        assert ((c1 | c2) == cu).all()
+        assert c1.sum() + c2.sum() == cu.sum()
+
+
+# ---- KA3: culling ---------------------------------------------------------------------------
+
+def test_ka3_quad_visible_from_minus_z_only():
+    for cam_z, yaw, visible in ((-2.0, 0.0, True), (2.0, math.pi, False)):
+        vs = oracle_server(W, H, threads=1)
+        vs.set_camera(from_translation((0, 0, cam_z)) @ from_rotation_y(yaw), Camera(aspect_ratio=W / H))
+        quad = vs.asset_server.add(Mesh.quad())
+        vs.set_mesh_instance(1, identity(), quad)
+        vs.render()
+        assert (vs.read_coverage().sum() > 0) == visible
+
+
+# ---- KA4: depth test is order independent ----------------------------------------------------
+
+def test_ka4_draw_order_does_not_change_image():
+    imgs = []
+    for order in ((1, 2), (2, 1)):
+        vs, cam = server()
+        tris = {1: ([(5, 5), (5, 40), (50, 5)], 2.0), 2: ([(10, 2), (10, 45), (60, 20)], [3.0, 1.5, 1.2])}
+        for node in order:
+            pts, z = tris[node]
+            screen_tri(vs, cam, pts, z=z, node=node)
+        vs.render()
+        imgs.append((vs.read_color_rgba8(), vs.read_depth()))
+    assert (imgs[0][0] == imgs[1][0]).all() and (imgs[0][1] == imgs[1][1]).all()
+
+
+def test_ka4_equal_depth_tie_goes_to_first_drawn():
+    vs, cam = server()
+    screen_tri(vs, cam, [(5, 5), (5, 40), (50, 5)], node=7)
+    screen_tri(vs, cam, [(5, 5), (5, 40), (50, 5)], node=3)    # identical, drawn second
+    vs.render()
+    ids = vs.read_triangle_ids()
+    assert set(np.unique(ids)) == {0, 0xFFFFFFFF}
+
+
+# ---- KA5-KA9: shading -------------------------------------------------------------------------
+
+SW, SH = 65, 49     # odd: the centre of pixel (32, 24) lies exactly on the optical axis
+
+
+def shading_scene(light=None, material=None, mode="deferred", tone=1):
+    """Big triangle in the plane z = 0 with normal -Z, camera at (0,0,-2) looking +Z."""
+    vs = oracle_server(SW, SH, mode=mode, threads=1)
+    vs.set_tone_mapping(tone)
+    vs.set_camera(from_translation((0, 0, -2.0)), Camera(aspect_ratio=SW / SH))
+    mat = vs.asset_server.add(material) if material is not None else None
+    v = make_vertices([(-50, -50, 0), (50, -50, 0), (0, 80, 0)], normals=[(0, 0, -1)] * 3)
+    # CCW with y up seen from -Z: (-50,-50) -> (50,-50) -> (0,80)
+    mesh = vs.asset_server.add(Mesh([Submesh(v, np.array([0, 1, 2], np.uint32), mat)]))
+    vs.set_mesh_instance(1, identity(), mesh)
+    if light is not None:
+        vs.set_light(9, light[0], light[1])
+    vs.render()
+    return vs
+
+
+def centre(vs):
+    return vs.read_color_hdr()[SH // 2, SW // 2]
+
+
+def test_ka5_point_light_blinn_phong_value():
+    # fragment ~ origin, n = (0,0,-1), camera (0,0,-2), point light (0,0,-1) r=4 colour (1,1,1,2):
+    # d = 1, lin = .75, att = .75^2*(3-1.5) = .84375, diff = 1, spec = 1
+    # light term = 2*.84375*(1+1) = 3.375 ; ambient = (.3,.5,.9)*.04
+    light = (from_translation((0, 0, -1.0)), Light.point(4.0).with_color(Color(1, 1, 1, 2.0)))
+    for mode in ("deferred", "forward"):
+        vs = shading_scene(light, mode=mode)
+        got = centre(vs)
+        want = np.array([0.012, 0.020, 0.036]) + 3.375
+        assert np.allclose(got, want, rtol=2e-3), (mode, got, want)     # f16 target: 11-bit mantissa
+        img = vs.read_color_rgba8()[SH // 2, SW // 2]
+        exp = [srgb8(v) for v in reinhard(list(want))]
+        assert all(abs(int(a) - b) <= 1 for a, b in zip(img[:3], exp)) and img[3] == 255
+
+
+def test_ka5_directional_light_value():
+    # directional light pointing +Z (transform = identity: z axis = (0,0,1)), colour (1,.9,.8,3.5):
+    # diff = dot(n, -L) = 1; h = normalize(-L + V) = (0,0,-1) at the axis -> spec = 1
+    light = (identity(), Light.directional().with_color(Color(1.0, 0.9, 0.8, 3.5)))
+    vs = shading_scene(light)
+    want = np.array([0.012, 0.020, 0.036]) + np.array([1.0, 0.9, 0.8]) * 3.5 * 2.0
+    assert np.allclose(centre(vs), want, rtol=2e-3)
+
+
+def test_ka6_point_light_cutoff_is_exact_zero():
+    light = (from_translation((0, 0, -1.0)), Light.point(0.5).with_color(Color(1, 1, 1, 2.0)))   # d=1 > r
+    for mode in ("deferred", "forward"):
+        vs = shading_scene(light, mode=mode)
+        hdr = vs.read_color_hdr()
+        cov = vs.read_coverage().astype(bool)
+        amb = np.array([0.012, 0.020, 0.036], dtype=np.float32)
+        assert np.allclose(hdr[cov], amb, rtol=1e-3)
+        assert len(np.unique(hdr[cov].reshape(-1, 3), axis=0)) == 1     # exactly the ambient term everywhere
+
+
+def test_ka7_alpha_test_discards_colour_and_depth():
+    vs = shading_scene(material=Material(base_color=Color(1, 1, 1, 0.49)))
+    assert vs.read_coverage().sum() == 0
+    assert (vs.read_depth() == 1.0).all()
+    vs = shading_scene(material=Material(base_color=Color(1, 1, 1, 0.5)))
+    assert vs.read_coverage().sum() > 0
+
+
+def test_ka8_unlit_material_is_base_colour_only():
+    light = (from_translation((0, 0, -1.0)), Light.point(4.0).with_color(Color(1, 1, 1, 2.0)))
+    for mode in ("deferred", "forward"):
+        vs = shading_scene(light, material=Material(base_color=Color(0.25, 0.5, 0.75, 1.0), unlit=True), mode=mode)
+        assert np.allclose(centre(vs), [0.25, 0.5, 0.75], rtol=1e-3)
+
+
+def test_ka9_tone_mapping():
+    # unlit white: (1,1,1) -> Reinhard 1/(1+1) = .5 -> sRGB 188 ; without tone mapping -> 255
+    vs = shading_scene(material=Material(unlit=True))
+    assert list(vs.read_color_rgba8()[SH // 2, SW // 2]) == [188, 188, 188, 255]
+    vs = shading_scene(material=Material(unlit=True), tone=0)
+    assert list(vs.read_color_rgba8()[SH // 2, SW // 2]) == [255, 255, 255, 255]
+    # background of an empty scene: Color::GRUE (.02,.04,.08) through f16, tone map and sRGB
+    f16 = lambda v: float(np.float16(v))
+    grue = [f16(0.02), f16(0.04), f16(0.08)]
+    for tone, want in ((0, grue), (1, reinhard(grue))):
+        vs = oracle_server(W, H, threads=1)
+        vs.set_tone_mapping(tone)
+        vs.render()
+        assert (vs.read_coverage() == 0).all() and (vs.read_depth() == 1.0).all()
+        assert list(vs.read_color_rgba8()[0, 0]) == [srgb8(c) for c in want] + [255]
+        assert np.allclose(vs.read_color_hdr()[3, 3], grue, rtol=0, atol=0)
+
+
+# ---- KA10: near-plane clipping -------------------------------------------------------------------
+
+def test_ka10_near_plane_clip_matches_analytic_polygon():
+    # Triangle in the plane y_view = -0.5 (a floor strip) running from behind the camera to z=10.
+    # After clipping at z = near, its projection is the polygon computed below in float64.
+    w, h = 96, 64
+    vs = oracle_server(w, h, threads=1)
+    cam = Camera(aspect_ratio=w / h)
+    vs.set_camera(identity(), cam)
+    tri = np.array([(1.0, -0.5, -3.0), (0.0, -0.5, 10.0), (-1.0, -0.5, -3.0)])   # on screen: right, apex, left = CCW
+    mesh = vs.asset_server.add(tri_mesh(tri, normals=[(0, 1, 0)] * 3))
+    vs.set_mesh_instance(1, identity(), mesh)
+    vs.render()
+    cov = vs.read_coverage().astype(bool)
+    assert cov.sum() > 0
+    # analytic: clip against z >= near in view space, project, point-in-polygon at pixel centres
+    near = cam.near
+    poly = []
+    for k in range(3):
+        a, b = tri[k], tri[(k + 1) % 3]
+        if a[2] >= near:
+            poly.append(a)
+        if (a[2] >= near) != (b[2] >= near):
+            t = (near - a[2]) / (b[2] - a[2])
+            poly.append(a + t * (b - a))
+    hh = 1.0 / math.tan(0.5 * cam.vfov)
+    ww = hh / cam.aspect_ratio
+    scr = np.array([((p[0] * ww / p[2] + 1) * 0.5 * w, (1 - p[1] * hh / p[2]) * 0.5 * h) for p in poly])
+    ys, xs = np.mgrid[0:h, 0:w]
+    cx, cy = xs + 0.5, ys + 0.5
+    inside = np.ones((h, w), bool)
+    margin = np.full((h, w), np.inf)
+    n = len(scr)
+    sign = None
+    for k in range(n):
+        (x0, y0), (x1, y1) = scr[k], scr[(k + 1) % n]
+        e = (x1 - x0) * (cy - y0) - (y1 - y0) * (cx - x0)
+        if sign is None:
+            sign = np.sign(e[(cy > scr[:, 1].min() + 1) & cov].mean())
+        inside &= (e * sign) > 0
+        margin = np.minimum(margin, np.abs(e) / math.hypot(x1 - x0, y1 - y0))
+    # pixels whose centre is more than 1/64 px from every polygon edge must agree exactly
+    safe = margin > 1 / 64
+    assert (cov[safe] == inside[safe]).all()
+    assert np.isfinite(vs.read_depth()).all()
+    assert (vs.read_depth()[cov] < 1.0).all() and (vs.read_depth()[cov] >= 0.0).all()
+
+
+# ---- KA11: the reference's forward multi-pass == the deferred formulation ---------------------------
+
+def test_ka11_forward_equals_deferred_on_random_scene():
+    rng = np.random.default_rng(11)
+    w, h = 160, 120
+    outs = {}
+    for mode in ("deferred", "forward"):
+        vs = oracle_server(w, h, mode=mode, threads=1)
+        cam = Camera(aspect_ratio=w / h)
+        vs.set_camera(from_translation((0, 0, -1.0)), cam)
+        r = np.random.default_rng(5)
+        for m in range(6):
+            n = 40
+            ctr = r.uniform((-2, -1.5, 2.0), (2, 1.5, 6.0), size=(n, 3))
+            pos = (ctr[:, None, :] + r.normal(scale=0.5, size=(n, 3, 3))).reshape(-1, 3)
+            nrm = r.normal(size=(n * 3, 3))
+            nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+            mat = vs.asset_server.add(Material(base_color=Color(*r.uniform(0.2, 1.0, 3), 1.0), unlit=(m == 5)))
+            mesh = vs.asset_server.add(Mesh([Submesh(make_vertices(pos, nrm), np.arange(n * 3, dtype=np.uint32), mat)]))
+            vs.set_mesh_instance(m + 1, from_translation(r.uniform(-0.2, 0.2, 3)), mesh)
+        for k in range(5):
+            p = r.uniform((-2, -2, 1), (2, 2, 5))
+            vs.set_light(50 + k, from_translation(p), Light.point(5.0).with_color(Color(*r.uniform(0.2, 1, 3), 2.0)))
+        vs.set_light(60, from_rotation_y(0.4), Light.directional().with_color(Color(1.0, 0.9, 0.8, 1.5)))
+        vs.render()
+        outs[mode] = (vs.read_color_rgba8().astype(int), vs.read_depth(), vs.read_coverage(), vs.read_color_hdr())
+    d, f = outs["deferred"], outs["forward"]
+    assert (d[2] == f[2]).all() and (d[1] == f[1]).all()
+    assert d[2].sum() > 1000
+    diff = np.abs(d[0] - f[0]).max(axis=-1)
+    assert (diff <= 1).mean() >= 0.999, (diff > 1).mean()
+    # HDR: at most a few f16 ulps (one rounding per light pass in the forward target)
+    rel = np.abs(d[3] - f[3]) / np.maximum(np.abs(f[3]), 1e-3)
+    assert np.percentile(rel, 99.9) < 6 * 2 ** -11
