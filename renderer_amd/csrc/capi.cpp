@@ -1,0 +1,193 @@
+// extern "C" boundary of include/rnd.h over rnd::VisualServer.  Exceptions never cross it: every
+// entry point returns an rnd_status and keeps the message for rnd_last_error().
+#include <cstring>
+#include <string>
+
+#include "../../include/rnd.h"
+#include "visual_server.hpp"
+
+struct rnd_ctx {
+    rnd::VisualServer* vs = nullptr;
+    std::string err;
+};
+
+static thread_local std::string g_create_error;
+
+template <class F>
+static int guard(rnd_ctx* ctx, F&& f) {
+    if (!ctx || !ctx->vs) return RND_ERR_INVALID;
+    try {
+        f(*ctx->vs);
+        return RND_OK;
+    } catch (const rnd::Error& e) {
+        ctx->err = e.what();
+        return e.status;
+    } catch (const std::bad_alloc&) {
+        ctx->err = "host allocation failed";
+        return RND_ERR_OOM;
+    } catch (const std::exception& e) {
+        ctx->err = e.what();
+        return RND_ERR_DEVICE;
+    }
+}
+template <class F>
+static int guard(const rnd_ctx* ctx, F&& f) { return guard(const_cast<rnd_ctx*>(ctx), f); }
+
+#define REQUIRE(ctx, cond, msg) \
+    if (!(cond)) { if (ctx) (ctx)->err = (msg); return RND_ERR_INVALID; }
+
+extern "C" {
+
+int rnd_create(rnd_ctx** out, uint32_t width, uint32_t height, int device) {
+    if (!out) { g_create_error = "rnd_create: null output pointer"; return RND_ERR_INVALID; }
+    *out = nullptr;
+    try {
+        rnd_ctx* c = new rnd_ctx();
+        try {
+            c->vs = new rnd::VisualServer(width, height, device);
+        } catch (...) {
+            delete c;
+            throw;
+        }
+        *out = c;
+        return RND_OK;
+    } catch (const rnd::Error& e) {
+        g_create_error = e.what();
+        return e.status;
+    } catch (const std::exception& e) {
+        g_create_error = e.what();
+        return RND_ERR_DEVICE;
+    }
+}
+
+void rnd_destroy(rnd_ctx* ctx) {
+    if (!ctx) return;
+    delete ctx->vs;
+    delete ctx;
+}
+
+const char* rnd_last_error(const rnd_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+const char* rnd_backend_name(void) { return "hip-gfx950"; }
+
+int rnd_render_size(const rnd_ctx* ctx, uint32_t* w, uint32_t* h) {
+    REQUIRE(const_cast<rnd_ctx*>(ctx), w && h, "null output");
+    return guard(ctx, [&](rnd::VisualServer& v) { v.render_size(*w, *h); });
+}
+int rnd_set_render_size(rnd_ctx* ctx, uint32_t w, uint32_t h) { return guard(ctx, [&](rnd::VisualServer& v) { v.set_render_size(w, h); }); }
+int rnd_render_size_factor(const rnd_ctx* ctx, float* f) {
+    REQUIRE(const_cast<rnd_ctx*>(ctx), f, "null output");
+    return guard(ctx, [&](rnd::VisualServer& v) { *f = v.render_size_factor(); });
+}
+int rnd_set_render_size_factor(rnd_ctx* ctx, float f) { return guard(ctx, [&](rnd::VisualServer& v) { v.set_render_size_factor(f); }); }
+int rnd_msaa_sample_count(const rnd_ctx* ctx, uint32_t* n) {
+    REQUIRE(const_cast<rnd_ctx*>(ctx), n, "null output");
+    return guard(ctx, [&](rnd::VisualServer& v) { *n = v.msaa_sample_count(); });
+}
+int rnd_set_msaa(rnd_ctx* ctx, uint32_t n) { return guard(ctx, [&](rnd::VisualServer& v) { v.set_msaa(n); }); }
+int rnd_tone_mapping(const rnd_ctx* ctx, uint32_t* m) {
+    REQUIRE(const_cast<rnd_ctx*>(ctx), m, "null output");
+    return guard(ctx, [&](rnd::VisualServer& v) { *m = v.tone_mapping(); });
+}
+int rnd_set_tone_mapping(rnd_ctx* ctx, uint32_t m) { return guard(ctx, [&](rnd::VisualServer& v) { v.set_tone_mapping(m); }); }
+
+int rnd_register_mesh(rnd_ctx* ctx, uint32_t mesh_id, uint32_t n, const rnd_submesh_desc* subs) {
+    return guard(ctx, [&](rnd::VisualServer& v) { v.register_mesh(mesh_id, n, subs); });
+}
+int rnd_register_material(rnd_ctx* ctx, uint32_t id, const float base_color[4], uint32_t billboard_mode, uint32_t unlit,
+                          uint32_t texture_id) {
+    REQUIRE(ctx, base_color, "null base colour");
+    return guard(ctx, [&](rnd::VisualServer& v) {
+        rnd::Material m;
+        std::memcpy(m.base_color, base_color, 16);
+        m.billboard_mode = billboard_mode; m.unlit = unlit != 0; m.texture = texture_id;
+        v.register_material(id, m);
+    });
+}
+int rnd_register_texture(rnd_ctx* ctx, uint32_t id, uint32_t w, uint32_t h, uint32_t mips, const uint8_t* data) {
+    return guard(ctx, [&](rnd::VisualServer& v) { v.register_texture(id, w, h, mips, data); });
+}
+
+int rnd_set_camera(rnd_ctx* ctx, const float t[16], float vfov, float aspect, float z_near, float z_far) {
+    REQUIRE(ctx, t, "null transform");
+    return guard(ctx, [&](rnd::VisualServer& v) {
+        v.set_camera(rnd::Mat4::from_cols_array(t), rnd::Camera{vfov, aspect, z_near, z_far});
+    });
+}
+int rnd_set_light(rnd_ctx* ctx, uint64_t id, const float t[16], const float color[4], uint32_t kind, float radius) {
+    REQUIRE(ctx, t && color, "null transform or colour");
+    return guard(ctx, [&](rnd::VisualServer& v) {
+        rnd::Light l;
+        std::memcpy(l.color, color, 16);
+        l.kind = kind; l.radius = radius;
+        v.set_light(id, rnd::Mat4::from_cols_array(t), l);
+    });
+}
+int rnd_set_mesh_instance(rnd_ctx* ctx, uint64_t id, const float t[16], uint32_t mesh_id) {
+    REQUIRE(ctx, t, "null transform");
+    return guard(ctx, [&](rnd::VisualServer& v) { v.set_mesh_instance(id, rnd::Mat4::from_cols_array(t), mesh_id, RND_NONE, true); });
+}
+int rnd_set_mesh_instance_ex(rnd_ctx* ctx, uint64_t id, const float t[16], uint32_t mesh_id, uint32_t material_override,
+                             uint32_t casts_shadows) {
+    REQUIRE(ctx, t, "null transform");
+    return guard(ctx, [&](rnd::VisualServer& v) {
+        v.set_mesh_instance(id, rnd::Mat4::from_cols_array(t), mesh_id, material_override, casts_shadows != 0);
+    });
+}
+int rnd_set_sprite(rnd_ctx* ctx, uint64_t id, const float t[16], uint32_t texture_id, const float color[4]) {
+    REQUIRE(ctx, t && color, "null transform or colour");
+    return guard(ctx, [&](rnd::VisualServer& v) { v.set_sprite(id, rnd::Mat4::from_cols_array(t), texture_id, color); });
+}
+int rnd_reset_scene(rnd_ctx* ctx) { return guard(ctx, [&](rnd::VisualServer& v) { v.reset_scene(); }); }
+
+int rnd_render(rnd_ctx* ctx) { return guard(ctx, [&](rnd::VisualServer& v) { v.render(); }); }
+int rnd_finish(rnd_ctx* ctx) { return guard(ctx, [&](rnd::VisualServer& v) { v.finish(); }); }
+
+int rnd_read_color_rgba8(rnd_ctx* ctx, uint8_t* dst) { return guard(ctx, [&](rnd::VisualServer& v) { v.read_color_rgba8(dst); }); }
+int rnd_read_color_hdr(rnd_ctx* ctx, float* dst) { return guard(ctx, [&](rnd::VisualServer& v) { v.read_color_hdr(dst); }); }
+int rnd_read_depth(rnd_ctx* ctx, float* dst) {
+    REQUIRE(ctx, dst, "null destination");
+    return guard(ctx, [&](rnd::VisualServer& v) { v.read_planes(dst, nullptr, nullptr); });
+}
+int rnd_read_coverage(rnd_ctx* ctx, uint8_t* dst) {
+    REQUIRE(ctx, dst, "null destination");
+    return guard(ctx, [&](rnd::VisualServer& v) { v.read_planes(nullptr, nullptr, dst); });
+}
+int rnd_read_triangle_ids(rnd_ctx* ctx, uint32_t* dst) {
+    REQUIRE(ctx, dst, "null destination");
+    return guard(ctx, [&](rnd::VisualServer& v) { v.read_planes(nullptr, dst, nullptr); });
+}
+int rnd_last_timings(rnd_ctx* ctx, rnd_timings* out) {
+    REQUIRE(ctx, out, "null output");
+    return guard(ctx, [&](rnd::VisualServer& v) { *out = v.last_timings(); });
+}
+int rnd_frame_stats_get(rnd_ctx* ctx, rnd_frame_stats* out) {
+    REQUIRE(ctx, out, "null output");
+    return guard(ctx, [&](rnd::VisualServer& v) { *out = v.frame_stats(); });
+}
+
+int rnd_set_tile_partition(rnd_ctx* ctx, uint32_t rank, uint32_t world) {
+    return guard(ctx, [&](rnd::VisualServer& v) { v.set_tile_partition(rank, world); });
+}
+int rnd_tile_info(const rnd_ctx* ctx, uint32_t* tile_px, uint32_t* n_owned, uint32_t* n_total) {
+    REQUIRE(const_cast<rnd_ctx*>(ctx), tile_px && n_owned && n_total, "null output");
+    return guard(ctx, [&](rnd::VisualServer& v) { v.tile_info(*tile_px, *n_owned, *n_total); });
+}
+int rnd_tiles_device_ptr(rnd_ctx* ctx, void** p, uint64_t* n) {
+    REQUIRE(ctx, p && n, "null output");
+    return guard(ctx, [&](rnd::VisualServer& v) { v.tiles_device_ptr(p, n); });
+}
+int rnd_detile(rnd_ctx* ctx, uint32_t src_rank, uint32_t world, const void* dev_tiles) {
+    return guard(ctx, [&](rnd::VisualServer& v) { v.detile(src_rank, world, dev_tiles); });
+}
+int rnd_packed_device_ptr(rnd_ctx* ctx, void** p, uint64_t* n) {
+    REQUIRE(ctx, p && n, "null output");
+    return guard(ctx, [&](rnd::VisualServer& v) { v.packed_device_ptr(p, n); });
+}
+int rnd_unpack(rnd_ctx* ctx, const void* dev_packed) { return guard(ctx, [&](rnd::VisualServer& v) { v.unpack(dev_packed); }); }
+int rnd_set_stream(rnd_ctx* ctx, void* s) { return guard(ctx, [&](rnd::VisualServer& v) { v.set_stream(static_cast<hipStream_t>(s)); }); }
+int rnd_color_device_ptr(rnd_ctx* ctx, void** p, uint64_t* n) {
+    REQUIRE(ctx, p && n, "null output");
+    return guard(ctx, [&](rnd::VisualServer& v) { v.color_device_ptr(p, n); });
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+// POD types shared by the host frame driver and the HIP kernels.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/rnd.h"
+
+namespace rnd {
+
+constexpr uint32_t kTile = 32;                 // square screen tile edge in pixels
+constexpr uint32_t kTilePixels = kTile * kTile;
+constexpr uint32_t kOwnerGroup = 4;            // sort-first ownership granularity, in tiles
+constexpr int kSubpixelBits = 8;
+constexpr int kSub = 1 << kSubpixelBits;       // 256 sub-pixel steps per pixel
+constexpr float kGuardBand = 16.0f;            // guard band half-extent in NDC units
+constexpr uint32_t kMaxRenderSize = 8192;      // tile coordinates are packed in 8 bits
+constexpr uint64_t kClearKey = (uint64_t(0x3F800000u) << 32) | 0xFFFFFFFFull;   // depth 1.0, no triangle
+constexpr uint32_t kMaxLights = 256;
+
+// flags of a draw item
+enum : uint32_t {
+    kItemBillboardMask = 3u,        // reference BillboardMode (material.rs:21-25)
+    kItemUnlit = 4u,                // MaterialUniform.unlit (visual_server.rs:983)
+    kItemSkip = 8u,                 // alpha test fails for every fragment (base.a < 0.5, untextured)
+    kItemCastsShadows = 16u,        // RenderMeshInstance.casts_shadows (visual_server.rs:961)
+};
+
+// One (instance, submesh) pair of VisualServer::render's draw list (visual_server.rs:225-245).
+struct DrawItem {
+    const float* px;            // SoA object-space positions, read by the vertex-transform kernel
+    const float* py;
+    const float* pz;
+    const rnd_vertex* verts;    // the reference's 32-byte AoS vertices, gathered when shading
+    const uint32_t* indices;    // u32 TriangleList
+    uint32_t n_verts;
+    uint32_t n_tris;
+    uint32_t vert_base;         // first slot of this item in the per-frame clip-position buffer
+    uint32_t tri_base;          // id of this item's first triangle (draw order)
+    float world[16];            // column-major matrix applied to positions (model, or the billboard basis)
+    float nrm[16];              // column-major matrix applied to normals (model, or identity)
+    float fixed_clip[4];        // billboard FixedSize: projected + divided anchor (render_mesh.wgsl:69-71)
+    float base_color[4];        // MaterialUniform.base_color
+    uint32_t flags;
+    uint32_t texture;           // index into the texture table, RND_NONE = white
+    uint32_t pad[2];
+};
+
+// LightUniform (visual_server.rs:987-996) reduced to what fs_main_blinn_phong reads.
+struct GpuLight {
+    float pos[3];       // transform.w.xyz (point lights)
+    float radius;
+    float dir[3];       // transform.z.xyz (directional lights), not normalized, as the shader
+    uint32_t kind;
+    float color[4];     // rgb + intensity
+    int32_t shadow_index;   // index of this light's cascade set, -1 = none
+    uint32_t pad[3];
+};
+
+// Per-frame constants passed by value to the kernels.
+struct FrameConst {
+    float pv[16];          // projection * view (render_mesh.wgsl:48)
+    float view[16];
+    float cam_pos[3];      // camera_transform.w.xyz
+    uint32_t tone;
+    float ambient[4];      // rgb + intensity (visual_server.rs:67)
+    float clear_hdr[3];    // Color::GRUE after the f16 target
+    uint32_t width, height;
+    uint32_t tiles_x, tiles_y;
+    uint32_t n_items, n_lights;
+    uint32_t n_tris, n_verts;
+    uint32_t rank, world;
+};
+
+// Setup record of one (sub-)triangle after cull / clip / snap: 48 bytes.
+struct SetupRecord {
+    int32_t x0, y0, x1, y1, x2, y2;    // snapped framebuffer positions, 8 sub-pixel bits
+    float z0, dz1, dz2;                // depth at v0 and deltas to v1, v2
+    float inv_area;                    // 1 / (double area in sub-pixel units)
+    uint32_t tri_id;                   // draw-order id of the source triangle
+    uint32_t flags;                    // bit 0: bbox below 64 px in x and y (32-bit edge functions are exact)
+};
+static_assert(sizeof(SetupRecord) == 48, "SetupRecord is 3 x 16 bytes");
+
+// Device-side counters of one frame.
+struct FrameCounters {
+    uint32_t n_records;        // setup records written
+    uint32_t n_clip;           // triangles queued for the clipper
+    uint32_t n_entries;        // bin entries (sum of tile counts)
+    uint32_t overflow;         // bit 0 records, bit 1 clip queue, bit 2 entries
+};
+
+struct Capacities {
+    uint32_t records, clip_queue, entries;
+};
+
+}  // namespace rnd

@@ -1,0 +1,61 @@
+// Launch interface of the HIP kernels (kernels.hip).  All launches are asynchronous on `stream`.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_types.h"
+
+namespace rnd {
+
+struct TileRef {
+    uint32_t tile;      // global tile index (ty * tiles_x + tx)
+    uint32_t compact;   // position of the tile in this rank's ascending list of owned tiles
+};
+
+struct FrameBuffers {
+    // per-frame scene tables
+    const DrawItem* items;
+    const uint32_t* vert_bases;     // n_items + 1
+    const uint32_t* tri_bases;      // n_items + 1
+    const GpuLight* lights;
+    // geometry stage
+    float4* clip;                   // n_verts clip positions
+    SetupRecord* records;
+    uint32_t* tilewords;            // per record: tx0 | ty0<<8 | (w-1)<<16 | (h-1)<<24
+    uint32_t* clip_queue;           // triangle ids that need the clipper
+    uint32_t* tile_count;           // per tile
+    uint32_t* tile_offset;          // per tile, exclusive scan of tile_count
+    uint32_t* tile_cursor;          // per tile, fill cursor
+    uint32_t* entries;              // bin entries: record slots, grouped by tile
+    FrameCounters* counters;
+    // pixel stage
+    const TileRef* launch_order;    // owned tiles in launch order (XCD-aware)
+    uint32_t n_owned;
+    uint64_t* vis;                  // tile-major (depth bits << 32 | triangle id), 1024 per tile
+    uint8_t* frame_rgba8;           // row-major RGBA8 frame (may be null)
+    uint8_t* tiles_rgba8;           // tile-major RGBA8 of owned tiles (may be null)
+    uint64_t* packed;               // row-major (depth bits << 32 | rgba8) (may be null)
+    float* hdr;                     // row-major f32 rgb (may be null; read-back only)
+};
+
+void launch_transform(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream);
+void launch_setup(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream);
+void launch_clip(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream);
+void launch_scan(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream);
+void launch_bin(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream);
+void launch_raster(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream);
+void launch_shade(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream);
+
+// read-back helpers: tile-major vis -> row-major planes (any pointer may be null)
+void launch_extract(const uint64_t* vis, const TileRef* order, uint32_t n_owned, const FrameConst& fc,
+                    float* depth, uint32_t* ids, uint8_t* coverage, hipStream_t stream);
+// AoS vertices -> SoA positions at mesh registration
+void launch_split_positions(const rnd_vertex* verts, uint32_t n, float* px, float* py, float* pz,
+                            hipStream_t stream);
+// tile-major RGBA8 of `n` tiles (list `tiles`) -> row-major frame
+void launch_detile(const uint8_t* tiles_rgba8, const uint32_t* tiles, uint32_t n, const FrameConst& fc,
+                   uint8_t* frame_rgba8, hipStream_t stream);
+// packed (depth | rgba8) row-major -> RGBA8 frame + tile-major vis depth
+void launch_unpack(const uint64_t* packed, const FrameConst& fc, uint8_t* frame_rgba8, float* depth,
+                   hipStream_t stream);
+
+}  // namespace rnd

@@ -1,0 +1,752 @@
+// HIP kernels of the frame hot path, written for gfx950 (CDNA4, wave64).
+//
+//   K1  k_transform   coalesced SoA vertex transform            (render_mesh.wgsl:42-82 vs_main)
+//   K2a k_setup       triangle setup: cull, snap, bbox, tile count, wave-compacted record stream
+//   K2c k_clip        Sutherland-Hodgman clipper for the (rare) triangles K2a queues
+//       k_scan_tiles  exclusive scan of the per-tile counts
+//   K2b k_bin_fill    scatter record slots into per-tile bins
+//   K3  k_raster      one workgroup per screen tile; depth|id staged in LDS, fixed-point edges
+//   K4  k_shade       deferred material/light shading + tone map + sRGB
+//                     (render_mesh.wgsl:86-111, :134-181, :256-281; show_texture.wgsl:40-61)
+//
+// The arithmetic that decides coverage and depth is integer or single IEEE f32 operations in a
+// fixed order (compiled with -ffp-contract=off; f32 divide and sqrt are correctly rounded by
+// hipcc's default), as DESIGN.md "Raster rules" states it, so results are reproducible bit for bit.
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace rnd {
+
+// ------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// largest k in [0, n) with bases[k] <= id (bases[0] == 0, ascending)
+__device__ __forceinline__ uint32_t find_item(const uint32_t* __restrict__ bases, uint32_t n, uint32_t id) {
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (bases[mid] <= id) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ bool owns_tile(uint32_t tx, uint32_t ty, uint32_t rank, uint32_t world) {
+    if (world <= 1) return true;
+    return (((tx / kOwnerGroup) + (ty / kOwnerGroup) * 3u) % world) == rank;
+}
+
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+    return (ax * bx + ay * by) + az * bz;
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: vertex transform.  One thread per (draw item, vertex); positions are read from three SoA
+// streams (4 B/lane, fully coalesced), the clip position is written as one 16-byte store per lane.
+// The draw item is made wave-uniform (waterfall over the rare waves that straddle two items) so
+// its matrices come in through scalar loads.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_transform(const DrawItem* __restrict__ items,
+                                                   const uint32_t* __restrict__ vert_bases, FrameConst fc,
+                                                   float4* __restrict__ clip) {
+    uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    if (gid >= fc.n_verts) return;
+    uint32_t it = find_item(vert_bases, fc.n_items, gid);
+    for (;;) {
+        uint32_t cur = __builtin_amdgcn_readfirstlane(it);
+        if (cur == it) {
+            const DrawItem& d = items[cur];
+            uint32_t v = gid - d.vert_base;
+            float x = d.px[v], y = d.py[v], z = d.pz[v];
+            float4 c;
+            if ((d.flags & kItemBillboardMask) == RND_BILLBOARD_FIXED_SIZE) {
+                c = make_float4(d.fixed_clip[0] + x * 0.4f, d.fixed_clip[1] + y * 0.4f, d.fixed_clip[2],
+                                d.fixed_clip[3]);
+            } else {
+                const float* m = d.world;
+                float wx = ((m[0] * x + m[4] * y) + m[8] * z) + m[12];
+                float wy = ((m[1] * x + m[5] * y) + m[9] * z) + m[13];
+                float wz = ((m[2] * x + m[6] * y) + m[10] * z) + m[14];
+                float ww = ((m[3] * x + m[7] * y) + m[11] * z) + m[15];
+                const float* p = fc.pv;
+                c.x = ((p[0] * wx + p[4] * wy) + p[8] * wz) + p[12] * ww;
+                c.y = ((p[1] * wx + p[5] * wy) + p[9] * wz) + p[13] * ww;
+                c.z = ((p[2] * wx + p[6] * wy) + p[10] * wz) + p[14] * ww;
+                c.w = ((p[3] * wx + p[7] * wy) + p[11] * wz) + p[15] * ww;
+            }
+            clip[gid] = c;
+            break;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: triangle setup
+// ------------------------------------------------------------------------------------------
+struct Snapped { int32_t x, y; float z; };
+
+__device__ __forceinline__ bool snap_vertex(float cx, float cy, float cz, float cw, float half_w,
+                                            float half_h, Snapped& s) {
+    if (!(cw > 0.0f)) return false;
+    float rw = 1.0f / cw;
+    float nx = cx * rw, ny = cy * rw, nz = cz * rw;
+    float sx = (nx + 1.0f) * half_w;
+    float sy = (1.0f - ny) * half_h;
+    s.x = (int32_t)rintf(sx * (float)kSub);
+    s.y = (int32_t)rintf(sy * (float)kSub);
+    s.z = nz;
+    return true;
+}
+
+struct TileRect { uint32_t tx0, ty0, tx1, ty1; };
+
+// Cull + bbox + record of one snapped triangle.  Returns false when nothing can be covered.
+__device__ __forceinline__ bool make_record(const Snapped& a, const Snapped& b, const Snapped& c,
+                                            uint32_t tri_id, const FrameConst& fc, SetupRecord& r,
+                                            TileRect& tr) {
+    long long A2 = (long long)(b.x - a.x) * (c.y - a.y) - (long long)(c.x - a.x) * (b.y - a.y);
+    long long area2 = -A2;
+    if (area2 <= 0) return false;
+    int32_t xmin = min(a.x, min(b.x, c.x)), xmax = max(a.x, max(b.x, c.x));
+    int32_t ymin = min(a.y, min(b.y, c.y)), ymax = max(a.y, max(b.y, c.y));
+    // pixel centres i*256+128 inside the closed bbox
+    int32_t i0 = max((xmin - kSub / 2 + kSub - 1) >> kSubpixelBits, 0);
+    int32_t i1 = min((xmax - kSub / 2) >> kSubpixelBits, (int32_t)fc.width - 1);
+    int32_t j0 = max((ymin - kSub / 2 + kSub - 1) >> kSubpixelBits, 0);
+    int32_t j1 = min((ymax - kSub / 2) >> kSubpixelBits, (int32_t)fc.height - 1);
+    if (i0 > i1 || j0 > j1) return false;
+    r.x0 = a.x; r.y0 = a.y; r.x1 = b.x; r.y1 = b.y; r.x2 = c.x; r.y2 = c.y;
+    r.z0 = a.z; r.dz1 = b.z - a.z; r.dz2 = c.z - a.z;
+    r.inv_area = 1.0f / (float)area2;
+    r.tri_id = tri_id;
+    r.flags = ((xmax - xmin) < (1 << 14) && (ymax - ymin) < (1 << 14)) ? 1u : 0u;
+    tr.tx0 = (uint32_t)i0 / kTile; tr.tx1 = (uint32_t)i1 / kTile;
+    tr.ty0 = (uint32_t)j0 / kTile; tr.ty1 = (uint32_t)j1 / kTile;
+    return true;
+}
+
+__device__ __forceinline__ uint32_t pack_tileword(const TileRect& t) {
+    return t.tx0 | (t.ty0 << 8) | ((t.tx1 - t.tx0) << 16) | ((t.ty1 - t.ty0) << 24);
+}
+
+__device__ __forceinline__ bool any_owned(const TileRect& t, const FrameConst& fc) {
+    if (fc.world <= 1) return true;
+    // rects spanning a whole ownership period in x or y always contain an owned tile
+    if (t.tx1 - t.tx0 >= kOwnerGroup * fc.world || t.ty1 - t.ty0 >= kOwnerGroup * fc.world) return true;
+    for (uint32_t ty = t.ty0; ty <= t.ty1; ++ty)
+        for (uint32_t tx = t.tx0; tx <= t.tx1; ++tx)
+            if (owns_tile(tx, ty, fc.rank, fc.world)) return true;
+    return false;
+}
+
+// Adds this wave's records to the per-tile counts (mode 0) or scatters them into the bins
+// (mode 1).  Lanes whose record touches one tile are grouped by tile with ballots: one atomic per
+// (wave, tile), each lane taking base + its rank inside the group.  Must be called by all lanes
+// of the wave that are still active, with `emit` false on lanes that have nothing.
+template <int MODE>
+__device__ __forceinline__ void bin_wave(bool emit, const TileRect& t, uint32_t slot, const FrameConst& fc,
+                                         uint32_t* __restrict__ tile_counter,
+                                         const uint32_t* __restrict__ tile_offset,
+                                         uint32_t* __restrict__ entries, uint32_t cap_entries) {
+    const uint32_t lane = lane_id();
+    bool single = emit && t.tx0 == t.tx1 && t.ty0 == t.ty1;
+    uint32_t tile = t.ty0 * fc.tiles_x + t.tx0;
+    if (single && !owns_tile(t.tx0, t.ty0, fc.rank, fc.world)) single = false, emit = false;
+    unsigned long long pending = __ballot(single);
+    while (pending) {
+        int leader = __ffsll((long long)pending) - 1;
+        uint32_t lt = __shfl(tile, leader);
+        unsigned long long same = __ballot(single && tile == lt);
+        uint32_t base = 0;
+        if (lane == (uint32_t)leader) base = atomicAdd(&tile_counter[lt], (uint32_t)__popcll(same));
+        if (MODE == 1) {
+            base = __shfl(base, leader);
+            if (single && tile == lt) {
+                uint32_t idx = tile_offset[lt] + base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+                if (idx < cap_entries) entries[idx] = slot;
+            }
+        }
+        pending &= ~same;
+    }
+    if (emit && !single) {
+        for (uint32_t ty = t.ty0; ty <= t.ty1; ++ty)
+            for (uint32_t tx = t.tx0; tx <= t.tx1; ++tx) {
+                if (!owns_tile(tx, ty, fc.rank, fc.world)) continue;
+                uint32_t tl = ty * fc.tiles_x + tx;
+                uint32_t pos = atomicAdd(&tile_counter[tl], 1u);
+                if (MODE == 1) {
+                    uint32_t idx = tile_offset[tl] + pos;
+                    if (idx < cap_entries) entries[idx] = slot;
+                }
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, FrameConst fc, Capacities cap) {
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t lane = lane_id();
+    bool emit = false, need_clip = false;
+    SetupRecord rec;
+    TileRect tr{0, 0, 0, 0};
+    if (gid < fc.n_tris) {
+        uint32_t it = find_item(fb.tri_bases, fc.n_items, gid);
+        const DrawItem& d = fb.items[it];
+        if (!(d.flags & kItemSkip)) {
+            uint32_t t = gid - d.tri_base;
+            const uint32_t* ix = d.indices + 3ull * t;
+            float4 c0 = fb.clip[d.vert_base + ix[0]];
+            float4 c1 = fb.clip[d.vert_base + ix[1]];
+            float4 c2 = fb.clip[d.vert_base + ix[2]];
+            bool finite = isfinite(c0.x) && isfinite(c0.y) && isfinite(c0.z) && isfinite(c0.w) &&
+                          isfinite(c1.x) && isfinite(c1.y) && isfinite(c1.z) && isfinite(c1.w) &&
+                          isfinite(c2.x) && isfinite(c2.y) && isfinite(c2.z) && isfinite(c2.w);
+            // trivial reject against the view volume
+            bool out = (c0.x < -c0.w && c1.x < -c1.w && c2.x < -c2.w) || (c0.x > c0.w && c1.x > c1.w && c2.x > c2.w) ||
+                       (c0.y < -c0.w && c1.y < -c1.w && c2.y < -c2.w) || (c0.y > c0.w && c1.y > c1.w && c2.y > c2.w) ||
+                       (c0.z < 0.0f && c1.z < 0.0f && c2.z < 0.0f) || (c0.z > c0.w && c1.z > c1.w && c2.z > c2.w);
+            if (finite && !out) {
+                float g0 = kGuardBand * c0.w, g1 = kGuardBand * c1.w, g2 = kGuardBand * c2.w;
+                need_clip = (c0.z < 0.0f) | (c0.z > c0.w) | (c0.x < -g0) | (c0.x > g0) | (c0.y < -g0) | (c0.y > g0) |
+                            (c1.z < 0.0f) | (c1.z > c1.w) | (c1.x < -g1) | (c1.x > g1) | (c1.y < -g1) | (c1.y > g1) |
+                            (c2.z < 0.0f) | (c2.z > c2.w) | (c2.x < -g2) | (c2.x > g2) | (c2.y < -g2) | (c2.y > g2);
+                if (!need_clip) {
+                    float half_w = 0.5f * (float)fc.width, half_h = 0.5f * (float)fc.height;
+                    Snapped s0, s1, s2;
+                    bool ok0 = snap_vertex(c0.x, c0.y, c0.z, c0.w, half_w, half_h, s0);
+                    bool ok1 = snap_vertex(c1.x, c1.y, c1.z, c1.w, half_w, half_h, s1);
+                    bool ok2 = snap_vertex(c2.x, c2.y, c2.z, c2.w, half_w, half_h, s2);
+                    if (ok0 && ok1 && ok2) emit = make_record(s0, s1, s2, gid, fc, rec, tr) && any_owned(tr, fc);
+                }
+            }
+        }
+    }
+    // queue the triangles that need the clipper (wave-compacted)
+    unsigned long long cm = __ballot(need_clip);
+    if (cm) {
+        int leader = __ffsll((long long)cm) - 1;
+        uint32_t base = 0;
+        if (lane == (uint32_t)leader) base = atomicAdd(&fb.counters->n_clip, (uint32_t)__popcll(cm));
+        base = __shfl(base, leader);
+        if (need_clip) {
+            uint32_t q = base + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull));
+            if (q < cap.clip_queue) fb.clip_queue[q] = gid; else atomicOr(&fb.counters->overflow, 2u);
+        }
+    }
+    // wave-compacted record stream: one atomic per wave
+    unsigned long long em = __ballot(emit);
+    uint32_t slot = 0;
+    if (em) {
+        int leader = __ffsll((long long)em) - 1;
+        uint32_t base = 0;
+        if (lane == (uint32_t)leader) base = atomicAdd(&fb.counters->n_records, (uint32_t)__popcll(em));
+        base = __shfl(base, leader);
+        slot = base + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
+        if (emit) {
+            if (slot < cap.records) {
+                float4* dst = reinterpret_cast<float4*>(fb.records + slot);
+                const float4* src = reinterpret_cast<const float4*>(&rec);
+                dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+                fb.tilewords[slot] = pack_tileword(tr);
+            } else {
+                atomicOr(&fb.counters->overflow, 1u);
+                emit = false;
+            }
+        }
+    }
+    bin_wave<0>(emit, tr, slot, fc, fb.tile_count, nullptr, nullptr, 0);
+}
+
+// --- clipper (rare path): near, far and the four guard-band planes, then a fan -------------
+struct ClipVert { float x, y, z, w; };
+
+__device__ __forceinline__ float plane_dist(const ClipVert& v, int plane) {
+    switch (plane) {
+        case 0: return v.z;
+        case 1: return v.w - v.z;
+        case 2: return v.x + kGuardBand * v.w;
+        case 3: return kGuardBand * v.w - v.x;
+        case 4: return v.y + kGuardBand * v.w;
+        default: return kGuardBand * v.w - v.y;
+    }
+}
+
+// evaluated from the inside vertex towards the outside one (watertight across shared edges)
+__device__ __forceinline__ ClipVert clip_intersect(const ClipVert& in, float din, const ClipVert& out, float dout) {
+    float t = din / (din - dout);
+    ClipVert r;
+    r.x = in.x + t * (out.x - in.x);
+    r.y = in.y + t * (out.y - in.y);
+    r.z = in.z + t * (out.z - in.z);
+    r.w = in.w + t * (out.w - in.w);
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_clip(FrameBuffers fb, FrameConst fc, Capacities cap) {
+    uint32_t n = min(fb.counters->n_clip, cap.clip_queue);
+    for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < n; q += gridDim.x * 256u) {
+        uint32_t gid = fb.clip_queue[q];
+        uint32_t it = find_item(fb.tri_bases, fc.n_items, gid);
+        const DrawItem& d = fb.items[it];
+        uint32_t t = gid - d.tri_base;
+        const uint32_t* ix = d.indices + 3ull * t;
+        ClipVert a[12], b[12];
+        for (int k = 0; k < 3; ++k) {
+            float4 c = fb.clip[d.vert_base + ix[k]];
+            a[k] = ClipVert{c.x, c.y, c.z, c.w};
+        }
+        int cnt = 3;
+        for (int plane = 0; plane < 6 && cnt >= 3; ++plane) {
+            int m = 0;
+            for (int k = 0; k < cnt; ++k) {
+                const ClipVert& p = a[k];
+                const ClipVert& nx = a[(k + 1 == cnt) ? 0 : k + 1];
+                float dp = plane_dist(p, plane), dn = plane_dist(nx, plane);
+                bool ip = dp >= 0.0f, in = dn >= 0.0f;
+                if (ip) b[m++] = p;
+                if (ip != in) b[m++] = ip ? clip_intersect(p, dp, nx, dn) : clip_intersect(nx, dn, p, dp);
+            }
+            cnt = m;
+            for (int k = 0; k < cnt; ++k) a[k] = b[k];
+        }
+        if (cnt < 3) continue;
+        float half_w = 0.5f * (float)fc.width, half_h = 0.5f * (float)fc.height;
+        Snapped s[12];
+        bool ok = true;
+        for (int k = 0; k < cnt; ++k) { bool o = snap_vertex(a[k].x, a[k].y, a[k].z, a[k].w, half_w, half_h, s[k]); ok = ok && o; }
+        if (!ok) continue;
+        for (int k = 1; k + 1 < cnt; ++k) {
+            SetupRecord rec;
+            TileRect tr;
+            if (!make_record(s[0], s[k], s[k + 1], gid, fc, rec, tr) || !any_owned(tr, fc)) continue;
+            uint32_t slot = atomicAdd(&fb.counters->n_records, 1u);
+            if (slot >= cap.records) { atomicOr(&fb.counters->overflow, 1u); continue; }
+            fb.records[slot] = rec;
+            fb.tilewords[slot] = pack_tileword(tr);
+            for (uint32_t ty = tr.ty0; ty <= tr.ty1; ++ty)
+                for (uint32_t tx = tr.tx0; tx <= tr.tx1; ++tx)
+                    if (owns_tile(tx, ty, fc.rank, fc.world)) atomicAdd(&fb.tile_count[ty * fc.tiles_x + tx], 1u);
+        }
+    }
+}
+
+// --- exclusive scan of the tile counts (one workgroup) --------------------------------------
+__global__ __launch_bounds__(1024) void k_scan_tiles(FrameBuffers fb, FrameConst fc, Capacities cap) {
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t n_tiles = fc.tiles_x * fc.tiles_y;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_tiles; base += 1024u) {
+        uint32_t i = base + tid;
+        uint32_t v = i < n_tiles ? fb.tile_count[i] : 0u;
+        uint32_t inc = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t up = __shfl_up(inc, o);
+            if (lane >= (uint32_t)o) inc += up;
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (uint32_t w = 0; w < wave; ++w) wave_off += s_wave[w];
+        uint32_t carry = s_carry;
+        if (i < n_tiles) {
+            fb.tile_offset[i] = carry + wave_off + inc - v;
+            fb.tile_cursor[i] = 0;
+        }
+        __syncthreads();
+        if (tid == 1023) s_carry = carry + wave_off + inc;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        fb.counters->n_entries = s_carry;
+        if (s_carry > cap.entries) atomicOr(&fb.counters->overflow, 4u);
+    }
+}
+
+// --- K2b: scatter record slots into the bins ---------------------------------------------
+__global__ __launch_bounds__(256) void k_bin_fill(FrameBuffers fb, FrameConst fc, Capacities cap) {
+    const uint32_t n = min(fb.counters->n_records, cap.records);
+    for (uint32_t r0 = blockIdx.x * 256u; r0 < n; r0 += gridDim.x * 256u) {
+        uint32_t r = r0 + threadIdx.x;
+        bool valid = r < n;
+        TileRect t{0, 0, 0, 0};
+        if (valid) {
+            uint32_t w = fb.tilewords[r];
+            t.tx0 = w & 255u; t.ty0 = (w >> 8) & 255u;
+            t.tx1 = t.tx0 + ((w >> 16) & 255u); t.ty1 = t.ty0 + (w >> 24);
+        }
+        bin_wave<1>(valid, t, r, fc, fb.tile_cursor, fb.tile_offset, fb.entries, cap.entries);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: per-tile raster.  One 256-thread workgroup per owned 32x32 tile; the tile's
+// (depth bits << 32 | triangle id) words live in LDS and fragments resolve with ds_min_u64, so the
+// nearest fragment wins and equal depths go to the first triangle in draw order, whatever order
+// the bin is processed in.  Small triangles (the bulk at C2..C5 density) are rasterized by one
+// lane each with 32-bit edge functions; the rest are queued in LDS and swept by a whole wave in
+// 8x8 pixel blocks with 64-bit edge functions.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kSmallPixels = 16;
+
+__device__ __forceinline__ void resolve(unsigned long long* s_vis, uint32_t local, float z, uint32_t id) {
+    z = fminf(fmaxf(z, 0.0f), 1.0f);
+    if (z < 1.0f) {
+        unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | id;
+        atomicMin(&s_vis[local], key);
+    }
+}
+
+__device__ __forceinline__ void raster_small(const SetupRecord& r, int32_t i0, int32_t i1, int32_t j0, int32_t j1,
+                                             int32_t tile_x0, int32_t tile_y0, unsigned long long* s_vis) {
+    // inside-positive edges: w0 = F(v2,v1,p), w1 = F(v0,v2,p), w2 = F(v1,v0,p)
+    const int32_t ex0 = r.x1 - r.x2, ey0 = r.y1 - r.y2;
+    const int32_t ex1 = r.x2 - r.x0, ey1 = r.y2 - r.y0;
+    const int32_t ex2 = r.x0 - r.x1, ey2 = r.y0 - r.y1;
+    const int32_t b0 = ((-ey0 > 0) || (ey0 == 0 && ex0 > 0)) ? 0 : 1;
+    const int32_t b1 = ((-ey1 > 0) || (ey1 == 0 && ex1 > 0)) ? 0 : 1;
+    const int32_t b2 = ((-ey2 > 0) || (ey2 == 0 && ex2 > 0)) ? 0 : 1;
+    const int32_t px = i0 * kSub + kSub / 2, py = j0 * kSub + kSub / 2;
+    int32_t r0 = ex0 * (py - r.y2) - ey0 * (px - r.x2);
+    int32_t r1 = ex1 * (py - r.y0) - ey1 * (px - r.x0);
+    int32_t r2 = ex2 * (py - r.y1) - ey2 * (px - r.x1);
+    for (int32_t j = j0; j <= j1; ++j) {
+        int32_t w0 = r0, w1 = r1, w2 = r2;
+        for (int32_t i = i0; i <= i1; ++i) {
+            if (w0 >= b0 && w1 >= b1 && w2 >= b2) {
+                float l1 = (float)w1 * r.inv_area, l2 = (float)w2 * r.inv_area;
+                float z = (l1 * r.dz1 + l2 * r.dz2) + r.z0;
+                resolve(s_vis, (uint32_t)((j - tile_y0) * (int32_t)kTile + (i - tile_x0)), z, r.tri_id);
+            }
+            w0 -= ey0 * kSub; w1 -= ey1 * kSub; w2 -= ey2 * kSub;
+        }
+        r0 += ex0 * kSub; r1 += ex1 * kSub; r2 += ex2 * kSub;
+    }
+}
+
+__device__ __forceinline__ void raster_wave(const SetupRecord& r, int32_t i0, int32_t i1, int32_t j0, int32_t j1,
+                                            int32_t tile_x0, int32_t tile_y0, unsigned long long* s_vis) {
+    const uint32_t lane = lane_id();
+    const int32_t lx = (int32_t)(lane & 7u), ly = (int32_t)(lane >> 3);
+    const int32_t ex0 = r.x1 - r.x2, ey0 = r.y1 - r.y2;
+    const int32_t ex1 = r.x2 - r.x0, ey1 = r.y2 - r.y0;
+    const int32_t ex2 = r.x0 - r.x1, ey2 = r.y0 - r.y1;
+    const long long b0 = ((-ey0 > 0) || (ey0 == 0 && ex0 > 0)) ? 0 : 1;
+    const long long b1 = ((-ey1 > 0) || (ey1 == 0 && ex1 > 0)) ? 0 : 1;
+    const long long b2 = ((-ey2 > 0) || (ey2 == 0 && ex2 > 0)) ? 0 : 1;
+    for (int32_t by = j0; by <= j1; by += 8)
+        for (int32_t bx = i0; bx <= i1; bx += 8) {
+            int32_t i = bx + lx, j = by + ly;
+            if (i > i1 || j > j1) continue;
+            int32_t px = i * kSub + kSub / 2, py = j * kSub + kSub / 2;
+            long long w0 = (long long)ex0 * (py - r.y2) - (long long)ey0 * (px - r.x2);
+            long long w1 = (long long)ex1 * (py - r.y0) - (long long)ey1 * (px - r.x0);
+            long long w2 = (long long)ex2 * (py - r.y1) - (long long)ey2 * (px - r.x1);
+            if (w0 >= b0 && w1 >= b1 && w2 >= b2) {
+                float l1 = (float)w1 * r.inv_area, l2 = (float)w2 * r.inv_area;
+                float z = (l1 * r.dz1 + l2 * r.dz2) + r.z0;
+                resolve(s_vis, (uint32_t)((j - tile_y0) * (int32_t)kTile + (i - tile_x0)), z, r.tri_id);
+            }
+        }
+}
+
+__device__ __forceinline__ SetupRecord load_record(const SetupRecord* __restrict__ recs, uint32_t slot) {
+    const float4* src = reinterpret_cast<const float4*>(recs + slot);
+    SetupRecord r;
+    float4* dst = reinterpret_cast<float4*>(&r);
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_raster(FrameBuffers fb, FrameConst fc, Capacities cap) {
+    __shared__ unsigned long long s_vis[kTilePixels];
+    __shared__ uint32_t s_big[256];
+    __shared__ uint32_t s_nbig;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tile = fb.launch_order[blockIdx.x].tile;
+    const int32_t tile_x0 = (int32_t)((tile % fc.tiles_x) * kTile), tile_y0 = (int32_t)((tile / fc.tiles_x) * kTile);
+    const int32_t tile_x1 = min(tile_x0 + (int32_t)kTile, (int32_t)fc.width) - 1;
+    const int32_t tile_y1 = min(tile_y0 + (int32_t)kTile, (int32_t)fc.height) - 1;
+    for (uint32_t k = tid; k < kTilePixels; k += 256u) s_vis[k] = kClearKey;
+    uint32_t off = fb.tile_offset[tile], n = fb.tile_count[tile];
+    if (off >= cap.entries) n = 0; else n = min(n, cap.entries - off);
+    __syncthreads();
+    for (uint32_t b = 0; b < n; b += 256u) {
+        if (tid == 0) s_nbig = 0;
+        __syncthreads();
+        uint32_t e = b + tid;
+        if (e < n) {
+            uint32_t slot = fb.entries[off + e];
+            SetupRecord r = load_record(fb.records, slot);
+            int32_t xmin = min(r.x0, min(r.x1, r.x2)), xmax = max(r.x0, max(r.x1, r.x2));
+            int32_t ymin = min(r.y0, min(r.y1, r.y2)), ymax = max(r.y0, max(r.y1, r.y2));
+            int32_t i0 = max((xmin - kSub / 2 + kSub - 1) >> kSubpixelBits, tile_x0);
+            int32_t i1 = min((xmax - kSub / 2) >> kSubpixelBits, tile_x1);
+            int32_t j0 = max((ymin - kSub / 2 + kSub - 1) >> kSubpixelBits, tile_y0);
+            int32_t j1 = min((ymax - kSub / 2) >> kSubpixelBits, tile_y1);
+            if (i0 <= i1 && j0 <= j1) {
+                uint32_t npix = (uint32_t)(i1 - i0 + 1) * (uint32_t)(j1 - j0 + 1);
+                if ((r.flags & 1u) && npix <= kSmallPixels) raster_small(r, i0, i1, j0, j1, tile_x0, tile_y0, s_vis);
+                else s_big[atomicAdd(&s_nbig, 1u)] = slot;
+            }
+        }
+        __syncthreads();
+        const uint32_t nbig = s_nbig;
+        for (uint32_t q = tid >> 6; q < nbig; q += 4u) {
+            SetupRecord r = load_record(fb.records, s_big[q]);
+            int32_t xmin = min(r.x0, min(r.x1, r.x2)), xmax = max(r.x0, max(r.x1, r.x2));
+            int32_t ymin = min(r.y0, min(r.y1, r.y2)), ymax = max(r.y0, max(r.y1, r.y2));
+            int32_t i0 = max((xmin - kSub / 2 + kSub - 1) >> kSubpixelBits, tile_x0);
+            int32_t i1 = min((xmax - kSub / 2) >> kSubpixelBits, tile_x1);
+            int32_t j0 = max((ymin - kSub / 2 + kSub - 1) >> kSubpixelBits, tile_y0);
+            int32_t j1 = min((ymax - kSub / 2) >> kSubpixelBits, tile_y1);
+            raster_wave(r, i0, i1, j0, j1, tile_x0, tile_y0, s_vis);
+        }
+        __syncthreads();
+    }
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(fb.vis) + (size_t)tile * kTilePixels;
+    for (uint32_t k = tid; k < kTilePixels; k += 256u) dst[k] = s_vis[k];
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: deferred shading.  One workgroup per owned tile, four pixels per lane.  Per pixel: the
+// winning triangle's three clip positions give perspective-correct barycentrics (2D homogeneous
+// edge functions, f64), the source vertices are gathered from the 32-byte AoS the reference
+// uploads, and the ambient + per-light Blinn-Phong sum is evaluated once in f32, rounded once to
+// f16 (the Rgba16Float target), tone-mapped and sRGB-encoded.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float round_f16(float x) { return __half2float(__float2half_rn(x)); }
+
+__device__ __forceinline__ uint32_t srgb8(float lin) {
+    float x = fminf(fmaxf(lin, 0.0f), 1.0f);
+    float y = (x <= 0.0031308f) ? 12.92f * x : 1.055f * powf(x, 1.0f / 2.4f) - 0.055f;
+    float q = y * 255.0f + 0.5f;
+    int v = (int)q;
+    return (uint32_t)min(max(v, 0), 255);
+}
+
+__device__ __forceinline__ void shade_pixel(const FrameBuffers& fb, const FrameConst& fc,
+                                            const GpuLight* __restrict__ lights, uint32_t id, uint32_t i,
+                                            uint32_t j, float hdr[3]) {
+    uint32_t it = find_item(fb.tri_bases, fc.n_items, id);
+    const DrawItem& d = fb.items[it];
+    uint32_t t = id - d.tri_base;
+    const uint32_t* ix = d.indices + 3ull * t;
+    uint32_t i0 = ix[0], i1 = ix[1], i2 = ix[2];
+    float4 c0 = fb.clip[d.vert_base + i0], c1 = fb.clip[d.vert_base + i1], c2 = fb.clip[d.vert_base + i2];
+    // barycentrics
+    double x0 = c0.x, y0 = c0.y, w0 = c0.w, x1 = c1.x, y1 = c1.y, w1 = c1.w, x2 = c2.x, y2 = c2.y, w2 = c2.w;
+    double xn = (2.0 * ((double)i + 0.5)) / (double)fc.width - 1.0;
+    double yn = 1.0 - (2.0 * ((double)j + 0.5)) / (double)fc.height;
+    double e0 = ((y1 * w2 - w1 * y2) * xn + (w1 * x2 - x1 * w2) * yn) + (x1 * y2 - y1 * x2);
+    double e1 = ((y2 * w0 - w2 * y0) * xn + (w2 * x0 - x2 * w0) * yn) + (x2 * y0 - y2 * x0);
+    double e2 = ((y0 * w1 - w0 * y1) * xn + (w0 * x1 - x0 * w1) * yn) + (x0 * y1 - y0 * x1);
+    double s = (e0 + e1) + e2;
+    double d0 = e0 / s, d1 = e1 / s, d2 = e2 / s;
+    if (!(isfinite(d0) && isfinite(d1) && isfinite(d2))) { d0 = 1.0; d1 = 0.0; d2 = 0.0; }
+    const float b0 = (float)d0, b1 = (float)d1, b2 = (float)d2;
+    // attributes, interpolated in object space
+    const rnd_vertex va = d.verts[i0], vb = d.verts[i1], vc = d.verts[i2];
+    float px = (b0 * va.position[0] + b1 * vb.position[0]) + b2 * vc.position[0];
+    float py = (b0 * va.position[1] + b1 * vb.position[1]) + b2 * vc.position[1];
+    float pz = (b0 * va.position[2] + b1 * vb.position[2]) + b2 * vc.position[2];
+    float nx = (b0 * va.normal[0] + b1 * vb.normal[0]) + b2 * vc.normal[0];
+    float ny = (b0 * va.normal[1] + b1 * vb.normal[1]) + b2 * vc.normal[1];
+    float nz = (b0 * va.normal[2] + b1 * vb.normal[2]) + b2 * vc.normal[2];
+    const float* m = d.world;
+    float fx = ((m[0] * px + m[4] * py) + m[8] * pz) + m[12];
+    float fy = ((m[1] * px + m[5] * py) + m[9] * pz) + m[13];
+    float fz = ((m[2] * px + m[6] * py) + m[10] * pz) + m[14];
+    const float* q = d.nrm;
+    float gx = (q[0] * nx + q[4] * ny) + q[8] * nz;
+    float gy = (q[1] * nx + q[5] * ny) + q[9] * nz;
+    float gz = (q[2] * nx + q[6] * ny) + q[10] * nz;
+    // base colour (untextured: the 1x1 white texture)
+    float br = d.base_color[0] * 1.0f, bg = d.base_color[1] * 1.0f, bb = d.base_color[2] * 1.0f;
+    float cr = br, cg = bg, cb = bb;
+    if (!(d.flags & kItemUnlit)) {
+        float ar = fc.ambient[0] * fc.ambient[3], ag = fc.ambient[1] * fc.ambient[3], ab = fc.ambient[2] * fc.ambient[3];
+        cr = br * ar; cg = bg * ag; cb = bb * ab;
+        float inv_n = 1.0f / sqrtf(dot3(gx, gy, gz, gx, gy, gz));
+        float Nx = gx * inv_n, Ny = gy * inv_n, Nz = gz * inv_n;
+        float vx = fc.cam_pos[0] - fx, vy = fc.cam_pos[1] - fy, vz = fc.cam_pos[2] - fz;
+        float inv_v = 1.0f / sqrtf(dot3(vx, vy, vz, vx, vy, vz));
+        float Vx = vx * inv_v, Vy = vy * inv_v, Vz = vz * inv_v;
+        for (uint32_t l = 0; l < fc.n_lights; ++l) {
+            const GpuLight& L = lights[l];
+            float dx, dy, dz, intensity;
+            if (L.kind == RND_LIGHT_DIRECTIONAL) {
+                dx = L.dir[0]; dy = L.dir[1]; dz = L.dir[2];
+                float occlusion = 0.0f;
+                intensity = L.color[3] * (1.0f - occlusion);
+            } else {
+                float ox = fx - L.pos[0], oy = fy - L.pos[1], oz = fz - L.pos[2];
+                float dist = sqrtf(dot3(ox, oy, oz, ox, oy, oz));
+                if (dist > L.radius) continue;
+                float inv_d = 1.0f / dist;
+                dx = ox * inv_d; dy = oy * inv_d; dz = oz * inv_d;
+                float lin = fminf(fmaxf((L.radius - dist) / L.radius, 0.0f), 1.0f);
+                float att = (lin * lin) * (3.0f - 2.0f * lin);
+                intensity = L.color[3] * att;
+            }
+            float tx = -dx, ty = -dy, tz = -dz;
+            float diff = fmaxf(dot3(Nx, Ny, Nz, tx, ty, tz), 0.0f);
+            float lr = L.color[0] * intensity, lg = L.color[1] * intensity, lb = L.color[2] * intensity;
+            float hx = tx + Vx, hy = ty + Vy, hz = tz + Vz;
+            float inv_h = 1.0f / sqrtf(dot3(hx, hy, hz, hx, hy, hz));
+            hx *= inv_h; hy *= inv_h; hz *= inv_h;
+            float sp = fmaxf(dot3(Nx, Ny, Nz, hx, hy, hz), 0.0f);
+            float s2 = sp * sp, s4 = s2 * s2, s8 = s4 * s4;
+            cr = cr + br * (lr * diff + lr * s8);
+            cg = cg + bg * (lg * diff + lg * s8);
+            cb = cb + bb * (lb * diff + lb * s8);
+        }
+    }
+    hdr[0] = round_f16(cr); hdr[1] = round_f16(cg); hdr[2] = round_f16(cb);
+}
+
+__global__ __launch_bounds__(256) void k_shade(FrameBuffers fb, FrameConst fc) {
+    __shared__ GpuLight s_lights[kMaxLights];
+    const uint32_t tid = threadIdx.x;
+    {
+        const uint32_t n_words = fc.n_lights * (uint32_t)(sizeof(GpuLight) / 4);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(fb.lights);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(s_lights);
+        for (uint32_t k = tid; k < n_words; k += 256u) dst[k] = src[k];
+    }
+    __syncthreads();
+    const TileRef ref = fb.launch_order[blockIdx.x];
+    const uint32_t tile_x0 = (ref.tile % fc.tiles_x) * kTile, tile_y0 = (ref.tile / fc.tiles_x) * kTile;
+    const unsigned long long* vis = reinterpret_cast<const unsigned long long*>(fb.vis) + (size_t)ref.tile * kTilePixels;
+    for (uint32_t k = 0; k < 4; ++k) {
+        uint32_t local = k * 256u + tid;
+        uint32_t i = tile_x0 + (local & (kTile - 1)), j = tile_y0 + (local / kTile);
+        bool inside = i < fc.width && j < fc.height;
+        unsigned long long key = vis[local];
+        uint32_t id = (uint32_t)(key & 0xFFFFFFFFull);
+        float hdr[3] = {fc.clear_hdr[0], fc.clear_hdr[1], fc.clear_hdr[2]};
+        if (inside && id != RND_NONE) shade_pixel(fb, fc, s_lights, id, i, j, hdr);
+        // show_texture.wgsl: Reinhard on luminance, then the sRGB surface
+        float r = hdr[0], g = hdr[1], b = hdr[2];
+        if (fc.tone == RND_TONE_MAPPING_REINHARD) {
+            float lum = (0.2126f * r + 0.7152f * g) + 0.0722f * b;
+            float dd = lum + 1.0f;
+            r = r / dd; g = g / dd; b = b / dd;
+        }
+        uint32_t rgba = srgb8(r) | (srgb8(g) << 8) | (srgb8(b) << 16) | 0xFF000000u;
+        if (fb.tiles_rgba8) reinterpret_cast<uint32_t*>(fb.tiles_rgba8)[(size_t)ref.compact * kTilePixels + local] = inside ? rgba : 0u;
+        if (inside) {
+            size_t p = (size_t)j * fc.width + i;
+            if (fb.frame_rgba8) reinterpret_cast<uint32_t*>(fb.frame_rgba8)[p] = rgba;
+            if (fb.packed) reinterpret_cast<unsigned long long*>(fb.packed)[p] = (key & 0xFFFFFFFF00000000ull) | rgba;
+            if (fb.hdr) { fb.hdr[p * 3] = hdr[0]; fb.hdr[p * 3 + 1] = hdr[1]; fb.hdr[p * 3 + 2] = hdr[2]; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// small utility kernels
+// ------------------------------------------------------------------------------------------
+__global__ void k_extract(const unsigned long long* __restrict__ vis, const TileRef* __restrict__ order, FrameConst fc,
+                          float* depth, uint32_t* ids, uint8_t* coverage) {
+    const TileRef ref = order[blockIdx.x];
+    const uint32_t tile_x0 = (ref.tile % fc.tiles_x) * kTile, tile_y0 = (ref.tile / fc.tiles_x) * kTile;
+    for (uint32_t local = threadIdx.x; local < kTilePixels; local += blockDim.x) {
+        uint32_t i = tile_x0 + (local & (kTile - 1)), j = tile_y0 + local / kTile;
+        if (i >= fc.width || j >= fc.height) continue;
+        unsigned long long key = vis[(size_t)ref.tile * kTilePixels + local];
+        size_t p = (size_t)j * fc.width + i;
+        uint32_t id = (uint32_t)(key & 0xFFFFFFFFull);
+        if (depth) depth[p] = __uint_as_float((uint32_t)(key >> 32));
+        if (ids) ids[p] = id;
+        if (coverage) coverage[p] = id != RND_NONE;
+    }
+}
+
+__global__ void k_split_positions(const rnd_vertex* __restrict__ verts, uint32_t n, float* px, float* py, float* pz) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    px[i] = verts[i].position[0];
+    py[i] = verts[i].position[1];
+    pz[i] = verts[i].position[2];
+}
+
+__global__ void k_detile(const uint32_t* __restrict__ tiles_rgba8, const uint32_t* __restrict__ tiles, FrameConst fc,
+                         uint32_t* frame) {
+    const uint32_t tile = tiles[blockIdx.x];
+    const uint32_t tile_x0 = (tile % fc.tiles_x) * kTile, tile_y0 = (tile / fc.tiles_x) * kTile;
+    for (uint32_t local = threadIdx.x; local < kTilePixels; local += blockDim.x) {
+        uint32_t i = tile_x0 + (local & (kTile - 1)), j = tile_y0 + local / kTile;
+        if (i < fc.width && j < fc.height) frame[(size_t)j * fc.width + i] = tiles_rgba8[(size_t)blockIdx.x * kTilePixels + local];
+    }
+}
+
+__global__ void k_unpack(const unsigned long long* __restrict__ packed, FrameConst fc, uint32_t* frame, float* depth) {
+    size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (size_t)fc.width * fc.height) return;
+    unsigned long long v = packed[p];
+    if (frame) frame[p] = (uint32_t)(v & 0xFFFFFFFFull);
+    if (depth) depth[p] = __uint_as_float((uint32_t)(v >> 32));
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+static inline uint32_t div_up(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
+
+void launch_transform(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream) {
+    if (!fc.n_verts) return;
+    hipLaunchKernelGGL(k_transform, dim3(div_up(fc.n_verts, 256)), dim3(256), 0, stream, fb.items, fb.vert_bases, fc, fb.clip);
+}
+void launch_setup(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {
+    if (!fc.n_tris) return;
+    hipLaunchKernelGGL(k_setup, dim3(div_up(fc.n_tris, 256)), dim3(256), 0, stream, fb, fc, cap);
+}
+void launch_clip(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {
+    if (!fc.n_tris) return;
+    uint32_t blocks = min(div_up(cap.clip_queue, 256), 1024u);
+    hipLaunchKernelGGL(k_clip, dim3(blocks), dim3(256), 0, stream, fb, fc, cap);
+}
+void launch_scan(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, stream, fb, fc, cap);
+}
+void launch_bin(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {
+    if (!fc.n_tris) return;
+    uint32_t blocks = min(div_up(cap.records, 256), 4096u);
+    hipLaunchKernelGGL(k_bin_fill, dim3(blocks), dim3(256), 0, stream, fb, fc, cap);
+}
+void launch_raster(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {
+    if (!fb.n_owned) return;
+    hipLaunchKernelGGL(k_raster, dim3(fb.n_owned), dim3(256), 0, stream, fb, fc, cap);
+}
+void launch_shade(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream) {
+    if (!fb.n_owned) return;
+    hipLaunchKernelGGL(k_shade, dim3(fb.n_owned), dim3(256), 0, stream, fb, fc);
+}
+void launch_extract(const uint64_t* vis, const TileRef* order, uint32_t n_owned, const FrameConst& fc, float* depth,
+                    uint32_t* ids, uint8_t* coverage, hipStream_t stream) {
+    if (!n_owned) return;
+    hipLaunchKernelGGL(k_extract, dim3(n_owned), dim3(256), 0, stream,
+                       reinterpret_cast<const unsigned long long*>(vis), order, fc, depth, ids, coverage);
+}
+void launch_split_positions(const rnd_vertex* verts, uint32_t n, float* px, float* py, float* pz, hipStream_t stream) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_split_positions, dim3(div_up(n, 256)), dim3(256), 0, stream, verts, n, px, py, pz);
+}
+void launch_detile(const uint8_t* tiles_rgba8, const uint32_t* tiles, uint32_t n, const FrameConst& fc,
+                   uint8_t* frame_rgba8, hipStream_t stream) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_detile, dim3(n), dim3(256), 0, stream, reinterpret_cast<const uint32_t*>(tiles_rgba8), tiles,
+                       fc, reinterpret_cast<uint32_t*>(frame_rgba8));
+}
+void launch_unpack(const uint64_t* packed, const FrameConst& fc, uint8_t* frame_rgba8, float* depth, hipStream_t stream) {
+    size_t n = (size_t)fc.width * fc.height;
+    hipLaunchKernelGGL(k_unpack, dim3(div_up(n, 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const unsigned long long*>(packed), fc, reinterpret_cast<uint32_t*>(frame_rgba8), depth);
+}
+
+}  // namespace rnd

@@ -1,0 +1,565 @@
+// Host frame driver: see visual_server.hpp.  reference: src/renderer/visual_server.rs,
+// src/renderer/pipeline3d.rs:261-368 (pass structure), src/renderer/backend.rs:455-498 (present).
+#include "visual_server.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+namespace rnd {
+
+void check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return;
+    std::string msg = std::string(what) + ": " + hipGetErrorString(e);
+    (void)hipGetLastError();
+    throw Error(e == hipErrorOutOfMemory ? RND_ERR_OOM : RND_ERR_DEVICE, msg);
+}
+#define HIP_CHECK(x) check_hip((x), #x)
+
+template <class T>
+void DeviceBuffer<T>::ensure(size_t n, bool keep) {
+    if (n <= count) return;
+    T* p = nullptr;
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T)));
+    if (ptr) {
+        if (keep && count) HIP_CHECK(hipMemcpy(p, ptr, count * sizeof(T), hipMemcpyDeviceToDevice));
+        (void)hipFree(ptr);   // waits for work that may still use the old allocation
+    }
+    ptr = p;
+    count = n;
+}
+template <class T>
+void DeviceBuffer<T>::release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    count = 0;
+}
+
+static constexpr uint32_t kQuadMeshId = 0xFFFFFFFEu;
+
+VisualServer::VisualServer(uint32_t width, uint32_t height, int device) : device_(device), width_(width), height_(height) {
+    if (width == 0 || height == 0 || width > kMaxRenderSize || height > kMaxRenderSize)
+        throw Error(RND_ERR_INVALID, "render size must be in 1..8192");
+    int n_dev = 0;
+    HIP_CHECK(hipGetDeviceCount(&n_dev));
+    if (device < 0 || device >= n_dev) throw Error(RND_ERR_INVALID, "no such HIP device");
+    use_device();
+    HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    for (auto& e : ev_) HIP_CHECK(hipEventCreate(&e));
+    for (auto& s : staging_) HIP_CHECK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_counters_), sizeof(FrameCounters), hipHostMallocDefault));
+    d_counters_.ensure(1);
+    // SceneUniform defaults — visual_server.rs:63-68
+    projection_ = perspective_lh(1.3f, 1.667f, 0.05f, 100.0f);
+    view_ = Mat4::identity();
+    camera_transform_ = Mat4::identity();
+    inv_projection_view_ = inverse(projection_ * view_);
+    rebuild_tiles();
+    // initialize_default_resources — visual_server.rs:865-873 (unit quad; default material is implicit)
+    static const rnd_vertex quad[4] = {{{-0.5f, 0.5f, 0.0f}, {0, 0, -1}, {0, 0}}, {{0.5f, 0.5f, 0.0f}, {0, 0, -1}, {1, 0}},
+                                       {{-0.5f, -0.5f, 0.0f}, {0, 0, -1}, {0, 1}}, {{0.5f, -0.5f, 0.0f}, {0, 0, -1}, {1, 1}}};
+    static const uint32_t quad_idx[6] = {0, 2, 1, 1, 2, 3};
+    rnd_submesh_desc d{quad, 4, quad_idx, 6, RND_NONE};
+    register_mesh(kQuadMeshId, 1, &d);
+}
+
+VisualServer::~VisualServer() {
+    (void)hipSetDevice(device_);
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    for (auto& kv : meshes_)
+        for (auto& s : kv.second.submeshes) { s.vertex_buffer.release(); s.positions.release(); s.index_buffer.release(); }
+    d_items_.release(); d_vert_bases_.release(); d_tri_bases_.release(); d_lights_.release(); d_clip_.release();
+    d_records_.release(); d_tilewords_.release(); d_clip_queue_.release(); d_tile_count_.release();
+    d_tile_offset_.release(); d_tile_cursor_.release(); d_entries_.release(); d_counters_.release();
+    d_launch_order_.release(); d_vis_.release(); d_frame_.release(); d_tiles_.release(); d_packed_.release();
+    d_hdr_.release(); d_detile_list_.release();
+    for (auto& s : staging_) {
+        if (s.host) (void)hipHostFree(s.host);
+        if (s.done) (void)hipEventDestroy(s.done);
+    }
+    if (h_counters_) (void)hipHostFree(h_counters_);
+    for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
+    if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
+}
+
+void VisualServer::use_device() const { HIP_CHECK(hipSetDevice(device_)); }
+
+// ---- settings ------------------------------------------------------------------------------
+void VisualServer::set_render_size(uint32_t w, uint32_t h) {
+    if (w == 0 || h == 0 || w > kMaxRenderSize || h > kMaxRenderSize) throw Error(RND_ERR_INVALID, "render size must be in 1..8192");
+    finish();
+    width_ = w; height_ = h;
+    have_frame_ = false;
+    rebuild_tiles();   // recreate_render_targets — visual_server.rs:621-662
+}
+void VisualServer::set_render_size_factor(float f) {
+    if (f != 1.0f) throw Error(RND_ERR_UNSUPPORTED, "render_size_factor != 1 not built yet (SURVEY §8f N4)");
+    render_size_factor_ = f;
+}
+void VisualServer::set_msaa(uint32_t n) {
+    if (n == 1) { msaa_ = 1; return; }
+    if (n == 4) throw Error(RND_ERR_UNSUPPORTED, "MSAA 4 not built yet (SURVEY §8f N4)");
+    throw Error(RND_ERR_INVALID, "sample count must be 1 or 4");
+}
+void VisualServer::set_tone_mapping(uint32_t m) {
+    if (m > 1) throw Error(RND_ERR_INVALID, "tone mapping must be 0 (None) or 1 (Reinhard)");
+    tone_mapping_ = m;
+}
+
+// ---- tiles -----------------------------------------------------------------------------------
+std::vector<uint32_t> VisualServer::owned_tiles(uint32_t rank, uint32_t world) const {
+    std::vector<uint32_t> out;
+    for (uint32_t ty = 0; ty < tiles_y_; ++ty)
+        for (uint32_t tx = 0; tx < tiles_x_; ++tx)
+            if (world <= 1 || (((tx / kOwnerGroup) + (ty / kOwnerGroup) * 3u) % world) == rank) out.push_back(ty * tiles_x_ + tx);
+    return out;
+}
+
+void VisualServer::rebuild_tiles() {
+    use_device();
+    tiles_x_ = (width_ + kTile - 1) / kTile;
+    tiles_y_ = (height_ + kTile - 1) / kTile;
+    std::vector<uint32_t> own = owned_tiles(rank_, world_);
+    n_owned_ = (uint32_t)own.size();
+    // Launch order: workgroups b and b+8 share an XCD (round-robin dispatch), so give every XCD one
+    // contiguous run of the row-major tile list; neighbouring tiles then share that XCD's L2.
+    std::vector<TileRef> order(n_owned_);
+    const uint32_t q = n_owned_ / 8, r = n_owned_ % 8;
+    for (uint32_t b = 0; b < n_owned_; ++b) {
+        uint32_t xcd = b % 8;
+        uint32_t idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
+        order[b] = TileRef{own[idx], idx};
+    }
+    d_launch_order_.ensure(std::max<size_t>(n_owned_, 1));
+    if (n_owned_) HIP_CHECK(hipMemcpy(d_launch_order_.ptr, order.data(), n_owned_ * sizeof(TileRef), hipMemcpyHostToDevice));
+    const size_t n_tiles = (size_t)tiles_x_ * tiles_y_;
+    d_tile_count_.ensure(n_tiles); d_tile_offset_.ensure(n_tiles); d_tile_cursor_.ensure(n_tiles);
+    d_vis_.ensure(n_tiles * kTilePixels);
+    d_frame_.ensure((size_t)width_ * height_ * 4);
+    if (world_ > 1) d_tiles_.ensure(std::max<size_t>((size_t)n_owned_ * kTilePixels * 4, 4));
+}
+
+void VisualServer::set_tile_partition(uint32_t rank, uint32_t world) {
+    if (world == 0 || rank >= world) throw Error(RND_ERR_INVALID, "rank must be < world");
+    finish();
+    rank_ = rank; world_ = world;
+    have_frame_ = false;
+    rebuild_tiles();
+}
+void VisualServer::tile_info(uint32_t& tile_px, uint32_t& n_owned, uint32_t& n_total) const {
+    tile_px = kTile; n_owned = n_owned_; n_total = tiles_x_ * tiles_y_;
+}
+
+// ---- resources -----------------------------------------------------------------------------
+void VisualServer::register_mesh(uint32_t mesh_id, uint32_t n_submeshes, const rnd_submesh_desc* subs) {
+    if (n_submeshes && !subs) throw Error(RND_ERR_INVALID, "null submesh array");
+    for (uint32_t k = 0; k < n_submeshes; ++k) {
+        const rnd_submesh_desc& d = subs[k];
+        if ((d.n_vertices && !d.vertices) || (d.n_indices && !d.indices) || d.n_indices % 3)
+            throw Error(RND_ERR_INVALID, "bad submesh (null pointer or index count not a multiple of 3)");
+        for (uint32_t i = 0; i < d.n_indices; ++i)
+            if (d.indices[i] >= d.n_vertices) throw Error(RND_ERR_INVALID, "vertex index out of range");
+    }
+    use_device();
+    finish();
+    auto old = meshes_.find(mesh_id);
+    if (old != meshes_.end()) {
+        for (auto& s : old->second.submeshes) { s.vertex_buffer.release(); s.positions.release(); s.index_buffer.release(); }
+        meshes_.erase(old);
+    }
+    RenderMesh mesh;
+    for (uint32_t k = 0; k < n_submeshes; ++k) {
+        const rnd_submesh_desc& d = subs[k];
+        RenderSubmesh s;
+        s.vertex_count = d.n_vertices; s.index_count = d.n_indices; s.material = d.material_id;
+        s.vertex_buffer.ensure(std::max<size_t>(d.n_vertices, 1));
+        s.positions.ensure(std::max<size_t>((size_t)d.n_vertices * 3, 1));
+        s.index_buffer.ensure(std::max<size_t>(d.n_indices, 1));
+        if (d.n_vertices) HIP_CHECK(hipMemcpyAsync(s.vertex_buffer.ptr, d.vertices, (size_t)d.n_vertices * sizeof(rnd_vertex), hipMemcpyHostToDevice, stream_));
+        if (d.n_indices) HIP_CHECK(hipMemcpyAsync(s.index_buffer.ptr, d.indices, (size_t)d.n_indices * 4, hipMemcpyHostToDevice, stream_));
+        // one-time AoS -> SoA transpose of the positions for the vertex-transform kernel
+        launch_split_positions(s.vertex_buffer.ptr, d.n_vertices, s.positions.ptr, s.positions.ptr + d.n_vertices,
+                               s.positions.ptr + 2 * (size_t)d.n_vertices, stream_);
+        mesh.submeshes.push_back(s);
+    }
+    HIP_CHECK(hipStreamSynchronize(stream_));   // the caller may free its arrays on return
+    meshes_[mesh_id] = std::move(mesh);
+}
+
+void VisualServer::register_material(uint32_t id, const Material& m) {
+    if (id == RND_NONE || m.billboard_mode > 2) throw Error(RND_ERR_INVALID, "bad material");
+    if (m.texture != RND_NONE) throw Error(RND_ERR_UNSUPPORTED, "textured materials not built yet (SURVEY §8f N2)");
+    materials_[id] = m;
+}
+void VisualServer::register_texture(uint32_t, uint32_t, uint32_t, uint32_t, const uint8_t*) {
+    throw Error(RND_ERR_UNSUPPORTED, "textures not built yet (SURVEY §8f N2)");
+}
+
+// ---- per-frame state -------------------------------------------------------------------------
+void VisualServer::set_camera(const Mat4& transform, const Camera& camera) {
+    projection_ = perspective_lh(camera.vfov, camera.aspect_ratio, camera.near, camera.far);
+    view_ = affine_inverse(transform);
+    inv_projection_view_ = inverse(projection_ * view_);
+    camera_transform_ = transform;
+}
+
+void VisualServer::set_light(UniqueNodeId id, const Mat4& transform, const Light& light) {
+    if (light.kind > 1) throw Error(RND_ERR_INVALID, "light kind must be 0 (directional) or 1 (point)");
+    Light l = light;
+    if (l.kind != RND_LIGHT_POINT) l.radius = 0.0f;   // Light::radius().unwrap_or_default()
+    for (auto& e : lights_)
+        if (e.id == id) { e.transform = transform; e.light = l; return; }
+    if (lights_.size() >= kMaxLights) throw Error(RND_ERR_INVALID, "too many lights (max 256)");
+    lights_.push_back(RenderLight{id, transform, l});
+}
+
+void VisualServer::set_mesh_instance(UniqueNodeId id, const Mat4& transform, uint32_t mesh_id, uint32_t material_override,
+                                     bool casts_shadows) {
+    if (!meshes_.count(mesh_id)) throw Error(RND_ERR_UNKNOWN_ID, "mesh id not registered");
+    if (material_override != RND_NONE && !materials_.count(material_override)) throw Error(RND_ERR_UNKNOWN_ID, "material id not registered");
+    RenderMeshInstance inst{id, transform, mesh_id, material_override, casts_shadows};
+    for (auto& e : mesh_instances_)
+        if (e.id == id) { e = inst; return; }
+    mesh_instances_.push_back(inst);
+}
+
+void VisualServer::set_sprite(UniqueNodeId id, const Mat4& transform, uint32_t texture_id, const float color[4]) {
+    if (texture_id != RND_NONE) throw Error(RND_ERR_UNSUPPORTED, "textured sprites not built yet (SURVEY §8f N2)");
+    uint32_t mid;
+    auto it = sprite_materials_.find(id);
+    if (it == sprite_materials_.end()) { mid = next_sprite_material_++; sprite_materials_[id] = mid; }
+    else mid = it->second;
+    Material m;
+    std::memcpy(m.base_color, color, 16);
+    m.billboard_mode = RND_BILLBOARD_ON; m.unlit = true; m.texture = texture_id;
+    materials_[mid] = m;
+    set_mesh_instance(id, transform, kQuadMeshId, mid, false);
+}
+
+void VisualServer::reset_scene() {
+    use_device();
+    finish();
+    for (auto it = meshes_.begin(); it != meshes_.end();) {
+        if (it->first == kQuadMeshId) { ++it; continue; }
+        for (auto& s : it->second.submeshes) { s.vertex_buffer.release(); s.positions.release(); s.index_buffer.release(); }
+        it = meshes_.erase(it);
+    }
+    materials_.clear(); lights_.clear(); mesh_instances_.clear(); sprite_materials_.clear();
+}
+
+// ---- frame -------------------------------------------------------------------------------------
+void VisualServer::build_frame(std::vector<DrawItem>& items, std::vector<uint32_t>& vert_bases,
+                               std::vector<uint32_t>& tri_bases, std::vector<GpuLight>& lights) {
+    const Mat4 pv = projection_ * view_;
+    uint64_t vert_base = 0, tri_base = 0;
+    // for mesh_instance { for submesh } — visual_server.rs:227-245
+    for (const RenderMeshInstance& inst : mesh_instances_) {
+        const RenderMesh& mesh = meshes_.at(inst.mesh);
+        for (const RenderSubmesh& s : mesh.submeshes) {
+            uint32_t mid = inst.material_override != RND_NONE ? inst.material_override : s.material;
+            Material mat;
+            if (mid != RND_NONE) {
+                auto it = materials_.find(mid);
+                if (it == materials_.end()) throw Error(RND_ERR_UNKNOWN_ID, "material id not registered");
+                mat = it->second;
+            }
+            DrawItem d{};
+            d.px = s.positions.ptr; d.py = s.positions.ptr + s.vertex_count; d.pz = s.positions.ptr + 2 * (size_t)s.vertex_count;
+            d.verts = s.vertex_buffer.ptr; d.indices = s.index_buffer.ptr;
+            d.n_verts = s.vertex_count; d.n_tris = s.index_count / 3;
+            d.vert_base = (uint32_t)vert_base; d.tri_base = (uint32_t)tri_base;
+            Mat4 world = inst.transform, nrm = inst.transform;
+            if (mat.billboard_mode == RND_BILLBOARD_ON) {            // render_mesh.wgsl:58-67
+                for (int j = 0; j < 3; ++j) {
+                    const Vec4& c = camera_transform_.col[j];
+                    world.col[j] = {c.x * 0.4f, c.y * 0.4f, c.z * 0.4f, c.w * 0.4f};
+                }
+                world.col[3] = inst.transform.col[3];
+            } else if (mat.billboard_mode == RND_BILLBOARD_FIXED_SIZE) {   // render_mesh.wgsl:68-79
+                const Vec4& o = inst.transform.col[3];
+                Vec4 vp = transform(pv, Vec4{o.x, o.y, o.z, 1.0f});
+                d.fixed_clip[0] = vp.x / vp.w; d.fixed_clip[1] = vp.y / vp.w; d.fixed_clip[2] = vp.z / vp.w; d.fixed_clip[3] = vp.w / vp.w;
+                nrm = Mat4::identity();
+            }
+            world.to_cols_array(d.world);
+            nrm.to_cols_array(d.nrm);
+            std::memcpy(d.base_color, mat.base_color, 16);
+            d.flags = mat.billboard_mode | (mat.unlit ? kItemUnlit : 0u) | (inst.casts_shadows ? kItemCastsShadows : 0u);
+            if (mat.base_color[3] * 1.0f < 0.5f) d.flags |= kItemSkip;   // alpha test, untextured (render_mesh.wgsl:91)
+            d.texture = mat.texture;
+            vert_bases.push_back(d.vert_base);
+            tri_bases.push_back(d.tri_base);
+            vert_base += d.n_verts; tri_base += d.n_tris;
+            if (vert_base >= 0xFFFFFFFFull || tri_base >= 0xFFFFFFFFull) throw Error(RND_ERR_INVALID, "frame exceeds 2^32 vertices or triangles");
+            items.push_back(d);
+        }
+    }
+    vert_bases.push_back((uint32_t)vert_base);
+    tri_bases.push_back((uint32_t)tri_base);
+    for (const RenderLight& l : lights_) {
+        GpuLight g{};
+        g.pos[0] = l.transform.col[3].x; g.pos[1] = l.transform.col[3].y; g.pos[2] = l.transform.col[3].z;
+        g.dir[0] = l.transform.col[2].x; g.dir[1] = l.transform.col[2].y; g.dir[2] = l.transform.col[2].z;
+        g.radius = l.light.radius; g.kind = l.light.kind;
+        std::memcpy(g.color, l.light.color, 16);
+        g.shadow_index = -1;
+        lights.push_back(g);
+    }
+    FrameConst& fc = fc_;
+    pv.to_cols_array(fc.pv);
+    view_.to_cols_array(fc.view);
+    fc.cam_pos[0] = camera_transform_.col[3].x; fc.cam_pos[1] = camera_transform_.col[3].y; fc.cam_pos[2] = camera_transform_.col[3].z;
+    fc.tone = tone_mapping_;
+    std::memcpy(fc.ambient, ambient_light_, 16);
+    fc.clear_hdr[0] = round_to_f16(0.02f); fc.clear_hdr[1] = round_to_f16(0.04f); fc.clear_hdr[2] = round_to_f16(0.08f);   // Color::GRUE
+    fc.width = width_; fc.height = height_; fc.tiles_x = tiles_x_; fc.tiles_y = tiles_y_;
+    fc.n_items = (uint32_t)items.size(); fc.n_lights = (uint32_t)lights.size();
+    fc.n_tris = (uint32_t)tri_base; fc.n_verts = (uint32_t)vert_base;
+    fc.rank = rank_; fc.world = world_;
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+void VisualServer::enqueue_frame(bool want_hdr) {
+    use_device();
+    std::vector<DrawItem> items;
+    std::vector<uint32_t> vert_bases, tri_bases;
+    std::vector<GpuLight> lights;
+    build_frame(items, vert_bases, tri_bases, lights);
+    const FrameConst& fc = fc_;
+    const size_t n_tiles = (size_t)tiles_x_ * tiles_y_;
+
+    // capacities
+    if (cap_.records < (uint64_t)fc.n_tris + fc.n_tris / 8 + 4096) cap_.records = fc.n_tris + fc.n_tris / 8 + 4096;
+    if (cap_.clip_queue < std::max<uint32_t>(fc.n_tris / 8, 65536)) cap_.clip_queue = std::max<uint32_t>(fc.n_tris / 8, 65536);
+    const uint64_t want_entries = std::max<uint64_t>(4ull * cap_.records + 16ull * n_tiles, 1u << 20);
+    if (cap_.entries < want_entries) cap_.entries = (uint32_t)std::min<uint64_t>(want_entries, 0xFFFFFFF0ull);
+    d_items_.ensure(std::max<size_t>(items.size(), 1));
+    d_vert_bases_.ensure(vert_bases.size()); d_tri_bases_.ensure(tri_bases.size());
+    d_lights_.ensure(std::max<size_t>(lights.size(), 1));
+    d_clip_.ensure(std::max<size_t>(fc.n_verts, 1));
+    d_records_.ensure(cap_.records); d_tilewords_.ensure(cap_.records);
+    d_clip_queue_.ensure(cap_.clip_queue);
+    d_entries_.ensure(cap_.entries);
+    if (world_ > 1) d_tiles_.ensure(std::max<size_t>((size_t)n_owned_ * kTilePixels * 4, 4));
+    if (want_packed_) d_packed_.ensure((size_t)width_ * height_);
+    if (want_hdr) d_hdr_.ensure((size_t)width_ * height_ * 3);
+
+    // stage the per-frame tables in pinned memory and upload them
+    const size_t off_items = 0;
+    const size_t off_vb = align_up(off_items + items.size() * sizeof(DrawItem), 256);
+    const size_t off_tb = align_up(off_vb + vert_bases.size() * 4, 256);
+    const size_t off_li = align_up(off_tb + tri_bases.size() * 4, 256);
+    const size_t total = align_up(off_li + lights.size() * sizeof(GpuLight), 256) + 256;
+    Staging& st = staging_[staging_next_];
+    staging_next_ = (staging_next_ + 1) % 3;
+    if (st.in_flight) { HIP_CHECK(hipEventSynchronize(st.done)); st.in_flight = false; }
+    if (st.bytes < total) {
+        if (st.host) HIP_CHECK(hipHostFree(st.host));
+        st.host = nullptr;
+        HIP_CHECK(hipHostMalloc(&st.host, total + total / 2, hipHostMallocDefault));
+        st.bytes = total + total / 2;
+    }
+    char* h = static_cast<char*>(st.host);
+    if (!items.empty()) std::memcpy(h + off_items, items.data(), items.size() * sizeof(DrawItem));
+    std::memcpy(h + off_vb, vert_bases.data(), vert_bases.size() * 4);
+    std::memcpy(h + off_tb, tri_bases.data(), tri_bases.size() * 4);
+    if (!lights.empty()) std::memcpy(h + off_li, lights.data(), lights.size() * sizeof(GpuLight));
+    if (!items.empty()) HIP_CHECK(hipMemcpyAsync(d_items_.ptr, h + off_items, items.size() * sizeof(DrawItem), hipMemcpyHostToDevice, stream_));
+    HIP_CHECK(hipMemcpyAsync(d_vert_bases_.ptr, h + off_vb, vert_bases.size() * 4, hipMemcpyHostToDevice, stream_));
+    HIP_CHECK(hipMemcpyAsync(d_tri_bases_.ptr, h + off_tb, tri_bases.size() * 4, hipMemcpyHostToDevice, stream_));
+    if (!lights.empty()) HIP_CHECK(hipMemcpyAsync(d_lights_.ptr, h + off_li, lights.size() * sizeof(GpuLight), hipMemcpyHostToDevice, stream_));
+    HIP_CHECK(hipEventRecord(st.done, stream_));
+    st.in_flight = true;
+
+    FrameBuffers fb{};
+    fb.items = d_items_.ptr; fb.vert_bases = d_vert_bases_.ptr; fb.tri_bases = d_tri_bases_.ptr; fb.lights = d_lights_.ptr;
+    fb.clip = d_clip_.ptr; fb.records = d_records_.ptr; fb.tilewords = d_tilewords_.ptr; fb.clip_queue = d_clip_queue_.ptr;
+    fb.tile_count = d_tile_count_.ptr; fb.tile_offset = d_tile_offset_.ptr; fb.tile_cursor = d_tile_cursor_.ptr;
+    fb.entries = d_entries_.ptr; fb.counters = d_counters_.ptr;
+    fb.launch_order = d_launch_order_.ptr; fb.n_owned = n_owned_;
+    fb.vis = d_vis_.ptr;
+    fb.frame_rgba8 = world_ > 1 ? nullptr : d_frame_.ptr;
+    fb.tiles_rgba8 = world_ > 1 ? d_tiles_.ptr : nullptr;
+    fb.packed = want_packed_ ? d_packed_.ptr : nullptr;
+    fb.hdr = want_hdr ? d_hdr_.ptr : nullptr;
+
+    HIP_CHECK(hipMemsetAsync(d_counters_.ptr, 0, sizeof(FrameCounters), stream_));
+    HIP_CHECK(hipMemsetAsync(d_tile_count_.ptr, 0, n_tiles * 4, stream_));
+    HIP_CHECK(hipEventRecord(ev_[0], stream_));
+    launch_transform(fb, fc, stream_);
+    HIP_CHECK(hipEventRecord(ev_[1], stream_));
+    launch_setup(fb, fc, cap_, stream_);
+    launch_clip(fb, fc, cap_, stream_);
+    HIP_CHECK(hipEventRecord(ev_[2], stream_));
+    launch_scan(fb, fc, cap_, stream_);
+    HIP_CHECK(hipEventRecord(ev_[3], stream_));
+    launch_bin(fb, fc, cap_, stream_);
+    HIP_CHECK(hipEventRecord(ev_[4], stream_));
+    launch_raster(fb, fc, cap_, stream_);
+    HIP_CHECK(hipEventRecord(ev_[5], stream_));
+    launch_shade(fb, fc, stream_);
+    HIP_CHECK(hipEventRecord(ev_[6], stream_));
+    HIP_CHECK(hipMemcpyAsync(h_counters_, d_counters_.ptr, sizeof(FrameCounters), hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipGetLastError());
+    frame_pending_ = true;
+    stats_ = rnd_frame_stats{};
+    stats_.n_vertices = fc.n_verts; stats_.n_triangles = fc.n_tris; stats_.n_draw_items = fc.n_items;
+    stats_.n_lights = fc.n_lights; stats_.n_tiles = n_owned_;
+    stats_.n_pixels = 0;
+}
+
+void VisualServer::render() { enqueue_frame(false); }
+
+void VisualServer::finish() {
+    if (!frame_pending_) return;
+    use_device();
+    uint32_t grew = 0;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        frame_pending_ = false;
+        const FrameCounters c = *h_counters_;
+        if (!c.overflow) break;
+        // an internal stream was too small: grow it to what the frame asked for and run it again
+        if (c.overflow & 1u) cap_.records = (uint32_t)std::min<uint64_t>((uint64_t)c.n_records + c.n_records / 4 + 4096, 0xFFFFFFF0ull);
+        if (c.overflow & 2u) cap_.clip_queue = (uint32_t)std::min<uint64_t>((uint64_t)c.n_clip + c.n_clip / 4 + 4096, 0xFFFFFFF0ull);
+        if (c.overflow & 4u) cap_.entries = (uint32_t)std::min<uint64_t>((uint64_t)c.n_entries + c.n_entries / 4 + 4096, 0xFFFFFFF0ull);
+        grew = 1;
+        if (attempt == 7) throw Error(RND_ERR_OOM, "frame does not fit the internal streams");
+        enqueue_frame(false);
+    }
+    const FrameCounters c = *h_counters_;
+    stats_.n_setup = c.n_records; stats_.n_bin_entries = c.n_entries; stats_.overflow = grew;
+    // pixels this context rasterizes: owned tiles clipped to the frame
+    uint64_t px = 0;
+    for (uint32_t t : owned_tiles(rank_, world_)) {
+        uint32_t tx = t % tiles_x_, ty = t / tiles_x_;
+        px += (uint64_t)std::min(kTile, width_ - tx * kTile) * std::min(kTile, height_ - ty * kTile);
+    }
+    stats_.n_pixels = px;
+    float ms[6] = {};
+    for (int k = 0; k < 6; ++k) HIP_CHECK(hipEventElapsedTime(&ms[k], ev_[k], ev_[k + 1]));
+    timings_ = rnd_timings{};
+    timings_.transform_ms = ms[0]; timings_.setup_ms = ms[1]; timings_.scan_ms = ms[2]; timings_.bin_ms = ms[3];
+    timings_.raster_ms = ms[4]; timings_.shade_ms = ms[5];
+    HIP_CHECK(hipEventElapsedTime(&timings_.frame_ms, ev_[0], ev_[6]));
+    have_frame_ = true;
+}
+
+void VisualServer::need_frame() const {
+    if (!have_frame_) throw Error(RND_ERR_NO_FRAME, "no frame rendered yet");
+}
+
+// ---- read-backs -----------------------------------------------------------------------------
+void VisualServer::read_color_rgba8(uint8_t* dst) {
+    if (!dst) throw Error(RND_ERR_INVALID, "null destination");
+    finish(); need_frame(); use_device();
+    if (world_ > 1) {   // a partitioned context holds only its tiles: assemble them over a cleared frame
+        HIP_CHECK(hipMemsetAsync(d_frame_.ptr, 0, (size_t)width_ * height_ * 4, stream_));
+        detile(rank_, world_, d_tiles_.ptr);
+    }
+    HIP_CHECK(hipMemcpyAsync(dst, d_frame_.ptr, (size_t)width_ * height_ * 4, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void VisualServer::read_color_hdr(float* dst) {
+    if (!dst) throw Error(RND_ERR_INVALID, "null destination");
+    finish(); need_frame(); use_device();
+    // the frame path never stores HDR; run the frame once more with the HDR plane attached
+    const size_t n = (size_t)width_ * height_ * 3;
+    d_hdr_.ensure(n);
+    enqueue_frame(true);
+    finish();
+    if (world_ > 1) {
+        // pixels outside the owned tiles are not written
+    }
+    HIP_CHECK(hipMemcpyAsync(dst, d_hdr_.ptr, n * 4, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void VisualServer::read_planes(float* depth, uint32_t* ids, uint8_t* coverage) {
+    finish(); need_frame(); use_device();
+    const size_t n = (size_t)width_ * height_;
+    DeviceBuffer<float> d_depth; DeviceBuffer<uint32_t> d_ids; DeviceBuffer<uint8_t> d_cov;
+    try {
+        if (depth) { d_depth.ensure(n); HIP_CHECK(hipMemsetAsync(d_depth.ptr, 0, n * 4, stream_)); }
+        if (ids) { d_ids.ensure(n); HIP_CHECK(hipMemsetAsync(d_ids.ptr, 0xFF, n * 4, stream_)); }
+        if (coverage) { d_cov.ensure(n); HIP_CHECK(hipMemsetAsync(d_cov.ptr, 0, n, stream_)); }
+        launch_extract(d_vis_.ptr, d_launch_order_.ptr, n_owned_, fc_, d_depth.ptr, d_ids.ptr, d_cov.ptr, stream_);
+        if (depth) HIP_CHECK(hipMemcpyAsync(depth, d_depth.ptr, n * 4, hipMemcpyDeviceToHost, stream_));
+        if (ids) HIP_CHECK(hipMemcpyAsync(ids, d_ids.ptr, n * 4, hipMemcpyDeviceToHost, stream_));
+        if (coverage) HIP_CHECK(hipMemcpyAsync(coverage, d_cov.ptr, n, hipMemcpyDeviceToHost, stream_));
+        HIP_CHECK(hipStreamSynchronize(stream_));
+    } catch (...) {
+        d_depth.release(); d_ids.release(); d_cov.release();
+        throw;
+    }
+    d_depth.release(); d_ids.release(); d_cov.release();
+}
+
+rnd_timings VisualServer::last_timings() { finish(); need_frame(); return timings_; }
+rnd_frame_stats VisualServer::frame_stats() { finish(); need_frame(); return stats_; }
+
+// ---- multi-GPU ---------------------------------------------------------------------------------
+void VisualServer::tiles_device_ptr(void** p, uint64_t* bytes) {
+    if (world_ <= 1) throw Error(RND_ERR_INVALID, "no tile partition set");
+    need_frame();
+    *p = d_tiles_.ptr; *bytes = (uint64_t)n_owned_ * kTilePixels * 4;
+}
+
+void VisualServer::detile(uint32_t src_rank, uint32_t world, const void* dev_tiles) {
+    if (!dev_tiles || world == 0 || src_rank >= world) throw Error(RND_ERR_INVALID, "bad detile arguments");
+    use_device();
+    std::vector<uint32_t> list = owned_tiles(src_rank, world);
+    if (list.empty()) return;
+    d_detile_list_.ensure(list.size());
+    // the list is consumed by the kernel below on the same stream; a pageable copy is synchronous
+    HIP_CHECK(hipMemcpyAsync(d_detile_list_.ptr, list.data(), list.size() * 4, hipMemcpyHostToDevice, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    FrameConst fc = fc_;
+    fc.width = width_; fc.height = height_; fc.tiles_x = tiles_x_; fc.tiles_y = tiles_y_;
+    launch_detile(static_cast<const uint8_t*>(dev_tiles), d_detile_list_.ptr, (uint32_t)list.size(), fc, d_frame_.ptr, stream_);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void VisualServer::packed_device_ptr(void** p, uint64_t* bytes) {
+    use_device();
+    if (!want_packed_ || !have_frame_) {
+        want_packed_ = true;
+        finish();
+        enqueue_frame(false);
+        finish();
+    }
+    *p = d_packed_.ptr; *bytes = (uint64_t)width_ * height_ * 8;
+}
+
+void VisualServer::unpack(const void* dev_packed) {
+    if (!dev_packed) throw Error(RND_ERR_INVALID, "null packed frame");
+    use_device();
+    FrameConst fc = fc_;
+    fc.width = width_; fc.height = height_;
+    launch_unpack(static_cast<const uint64_t*>(dev_packed), fc, d_frame_.ptr, nullptr, stream_);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    have_frame_ = true;
+}
+
+void VisualServer::set_stream(hipStream_t s) {
+    use_device();
+    finish();
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    if (own_stream_ && stream_) HIP_CHECK(hipStreamDestroy(stream_));
+    if (s) { stream_ = s; own_stream_ = false; }
+    else { HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking)); own_stream_ = true; }
+}
+
+void VisualServer::color_device_ptr(void** p, uint64_t* bytes) {
+    *p = d_frame_.ptr; *bytes = (uint64_t)width_ * height_ * 4;
+}
+
+template struct DeviceBuffer<float>;
+template struct DeviceBuffer<uint32_t>;
+template struct DeviceBuffer<uint8_t>;
+
+}  // namespace rnd

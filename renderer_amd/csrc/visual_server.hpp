@@ -1,0 +1,191 @@
+// Host side of the frame hot path: a C++ restatement of the reference's `VisualServer`
+// (src/renderer/visual_server.rs:30-874) with the wgpu plumbing replaced by HIP allocations and
+// kernel launches.  Method names and argument meaning follow the reference; the C ABI in capi.cpp
+// is a 1:1 wrapper.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "device_types.h"
+#include "kernels.h"
+#include "rnd_math.hpp"
+
+namespace rnd {
+
+struct Error : std::runtime_error {
+    int status;
+    Error(int s, const std::string& m) : std::runtime_error(m), status(s) {}
+};
+
+void check_hip(hipError_t e, const char* what);
+
+using UniqueNodeId = uint64_t;   // src/scene.rs:14-15 flattened to 64 bits
+
+struct Camera {                  // src/camera.rs:4-9
+    float vfov = 1.3f, aspect_ratio = 1.667f, near = 0.05f, far = 100.0f;
+};
+struct Light {                   // src/light.rs:3-7, kind id as LightKind::id()
+    float color[4] = {1, 1, 1, 1};
+    uint32_t kind = RND_LIGHT_POINT;
+    float radius = 1.0f;
+};
+struct Material {                // src/material.rs:3-8
+    float base_color[4] = {1, 1, 1, 1};
+    uint32_t billboard_mode = RND_BILLBOARD_OFF;
+    bool unlit = false;
+    uint32_t texture = RND_NONE;
+};
+
+template <class T>
+struct DeviceBuffer {
+    T* ptr = nullptr;
+    size_t count = 0;
+    void ensure(size_t n, bool keep = false);
+    void release();
+};
+
+struct RenderSubmesh {           // visual_server.rs:948-953
+    DeviceBuffer<rnd_vertex> vertex_buffer;
+    DeviceBuffer<float> positions;       // px | py | pz, n_verts each
+    DeviceBuffer<uint32_t> index_buffer;
+    uint32_t index_count = 0, vertex_count = 0;
+    uint32_t material = RND_NONE;
+};
+struct RenderMesh { std::vector<RenderSubmesh> submeshes; };
+struct RenderLight { UniqueNodeId id; Mat4 transform; Light light; };
+struct RenderMeshInstance {      // visual_server.rs:955-962
+    UniqueNodeId id;
+    Mat4 transform;
+    uint32_t mesh;
+    uint32_t material_override;
+    bool casts_shadows;
+};
+
+class VisualServer {
+public:
+    VisualServer(uint32_t width, uint32_t height, int device);
+    ~VisualServer();
+    VisualServer(const VisualServer&) = delete;
+
+    // settings — visual_server.rs:156-190
+    void render_size(uint32_t& w, uint32_t& h) const { w = width_; h = height_; }
+    void set_render_size(uint32_t w, uint32_t h);
+    float render_size_factor() const { return render_size_factor_; }
+    void set_render_size_factor(float f);
+    uint32_t msaa_sample_count() const { return msaa_; }
+    void set_msaa(uint32_t n);
+    uint32_t tone_mapping() const { return tone_mapping_; }
+    void set_tone_mapping(uint32_t m);
+
+    // resources — visual_server.rs:664-769
+    void register_mesh(uint32_t mesh_id, uint32_t n_submeshes, const rnd_submesh_desc* submeshes);
+    void register_material(uint32_t material_id, const Material& m);
+    void register_texture(uint32_t id, uint32_t w, uint32_t h, uint32_t mips, const uint8_t* data);
+
+    // per-frame state — visual_server.rs:206-222, :350-474, :481-550, :579-581
+    void set_camera(const Mat4& transform, const Camera& camera);
+    void set_light(UniqueNodeId id, const Mat4& transform, const Light& light);
+    void set_mesh_instance(UniqueNodeId id, const Mat4& transform, uint32_t mesh_id, uint32_t material_override,
+                           bool casts_shadows);
+    void set_sprite(UniqueNodeId id, const Mat4& transform, uint32_t texture_id, const float color[4]);
+    void reset_scene();
+
+    // frame — visual_server.rs:224-311
+    void render();
+    void finish();
+
+    // read-backs
+    void read_color_rgba8(uint8_t* dst);
+    void read_color_hdr(float* dst);
+    void read_planes(float* depth, uint32_t* ids, uint8_t* coverage);
+    rnd_timings last_timings();
+    rnd_frame_stats frame_stats();
+
+    // multi-GPU
+    void set_tile_partition(uint32_t rank, uint32_t world);
+    void tile_info(uint32_t& tile_px, uint32_t& n_owned, uint32_t& n_total) const;
+    void tiles_device_ptr(void** p, uint64_t* bytes);
+    void detile(uint32_t src_rank, uint32_t world, const void* dev_tiles);
+    void packed_device_ptr(void** p, uint64_t* bytes);
+    void unpack(const void* dev_packed);
+    void set_stream(hipStream_t s);
+    void color_device_ptr(void** p, uint64_t* bytes);
+
+    // for tests of the host logic
+    const Mat4& projection() const { return projection_; }
+    const Mat4& view() const { return view_; }
+
+private:
+    void use_device() const;
+    void rebuild_tiles();
+    std::vector<uint32_t> owned_tiles(uint32_t rank, uint32_t world) const;
+    void build_frame(std::vector<DrawItem>& items, std::vector<uint32_t>& vert_bases, std::vector<uint32_t>& tri_bases,
+                     std::vector<GpuLight>& lights);
+    void enqueue_frame(bool want_hdr);
+    void need_frame() const;
+
+    int device_;
+    uint32_t width_, height_;
+    float render_size_factor_ = 1.0f;
+    uint32_t msaa_ = 1;
+    uint32_t tone_mapping_ = RND_TONE_MAPPING_REINHARD;
+    uint32_t rank_ = 0, world_ = 1;
+    bool want_packed_ = false;
+
+    hipStream_t stream_ = nullptr;
+    bool own_stream_ = true;
+    hipEvent_t ev_[9] = {};
+
+    // RenderScene — visual_server.rs:896-905 (insertion-ordered instead of HashMap order)
+    std::unordered_map<uint32_t, RenderMesh> meshes_;
+    std::unordered_map<uint32_t, Material> materials_;
+    std::vector<RenderLight> lights_;
+    std::vector<RenderMeshInstance> mesh_instances_;
+    std::unordered_map<UniqueNodeId, uint32_t> sprite_materials_;
+    uint32_t next_sprite_material_ = 0x80000000u;
+
+    // SceneUniform — visual_server.rs:887-894
+    Mat4 projection_, view_, camera_transform_;
+    Mat4 inv_projection_view_;
+    float ambient_light_[4] = {0.3f, 0.5f, 0.9f, 0.04f};
+
+    // device state
+    DeviceBuffer<DrawItem> d_items_;
+    DeviceBuffer<uint32_t> d_vert_bases_, d_tri_bases_;
+    DeviceBuffer<GpuLight> d_lights_;
+    DeviceBuffer<float4> d_clip_;
+    DeviceBuffer<SetupRecord> d_records_;
+    DeviceBuffer<uint32_t> d_tilewords_, d_clip_queue_, d_tile_count_, d_tile_offset_, d_tile_cursor_, d_entries_;
+    DeviceBuffer<FrameCounters> d_counters_;
+    DeviceBuffer<TileRef> d_launch_order_;
+    DeviceBuffer<uint64_t> d_vis_;
+    DeviceBuffer<uint8_t> d_frame_, d_tiles_;
+    DeviceBuffer<uint64_t> d_packed_;
+    DeviceBuffer<float> d_hdr_;
+    DeviceBuffer<uint32_t> d_detile_list_;
+    Capacities cap_{0, 0, 0};
+
+    // pinned staging ring for the per-frame tables
+    struct Staging {
+        void* host = nullptr;
+        size_t bytes = 0;
+        hipEvent_t done = nullptr;
+        bool in_flight = false;
+    };
+    Staging staging_[3];
+    uint32_t staging_next_ = 0;
+    FrameCounters* h_counters_ = nullptr;   // pinned
+
+    uint32_t tiles_x_ = 0, tiles_y_ = 0, n_owned_ = 0;
+    bool have_frame_ = false, frame_pending_ = false;
+    FrameConst fc_{};
+    rnd_frame_stats stats_{};
+    rnd_timings timings_{};
+};
+
+}  // namespace rnd

@@ -1,0 +1,180 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Bar (BASELINE.json north_star): coverage masks bit-exact, depth within 1e-5, colour within 1/255
+on >= 99.9 % of pixels.  The integer/depth part is required to be bit-exact here (coverage, winning
+triangle id and depth bits), colour within 1 LSB everywhere, HDR within 1e-5 relative.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from renderer_amd import VisualServer
+from renderer_amd.scenes import SceneDesc, c1_sphere, c2_grid_1m, c3_grid_10m, uv_sphere_mesh
+from renderer_amd.types import (Camera, Color, Light, Material, Mesh, Submesh, from_rotation_x, from_rotation_y,
+                                from_scale, from_translation, identity)
+from tests.helpers import make_vertices, oracle_server
+
+pytestmark = pytest.mark.gpu
+
+
+def render_pair(scene: SceneDesc, tone=1, materials=None):
+    out = []
+    for make in (lambda: VisualServer(scene.width, scene.height, device=0), lambda: oracle_server(scene.width, scene.height)):
+        vs = make()
+        vs.set_tone_mapping(tone)
+        scene.populate(vs)
+        vs.render()
+        out.append(vs)
+    assert out[0].backend_name == "hip-gfx950" and out[1].backend_name == "cpu-oracle"
+    return out
+
+
+def assert_parity(gpu, cpu, min_covered=1, hdr=True):
+    cov_g, cov_c = gpu.read_coverage(), cpu.read_coverage()
+    assert cov_c.sum() >= min_covered
+    assert (cov_g == cov_c).all(), f"coverage differs on {(cov_g != cov_c).sum()} pixels"
+    ids_g, ids_c = gpu.read_triangle_ids(), cpu.read_triangle_ids()
+    assert (ids_g == ids_c).all(), f"winning triangle differs on {(ids_g != ids_c).sum()} pixels"
+    d_g, d_c = gpu.read_depth(), cpu.read_depth()
+    assert (d_g.view(np.uint32) == d_c.view(np.uint32)).all(), f"depth bits differ, max abs {np.abs(d_g - d_c).max()}"
+    img_g, img_c = gpu.read_color_rgba8().astype(int), cpu.read_color_rgba8().astype(int)
+    diff = np.abs(img_g - img_c).max(axis=-1)
+    assert diff.max() <= 1, f"colour differs by {diff.max()} on {(diff > 1).sum()} pixels"
+    if hdr:
+        h_g, h_c = gpu.read_color_hdr(), cpu.read_color_hdr()
+        rel = np.abs(h_g - h_c) / np.maximum(np.abs(h_c), 1e-3)
+        assert rel.max() <= 2 ** -10, f"HDR differs, max rel {rel.max()}"      # at most one f16 ulp
+        assert (rel > 0).mean() < 1e-3
+    return diff
+
+
+def soup_scene(seed, w, h, n_meshes=5, n_tri=60, spread=(2.5, 2.0), depth=(0.3, 8.0), size=0.6, lights=4, cam_z=-1.0):
+    r = np.random.default_rng(seed)
+    s = SceneDesc(f"soup{seed}", w, h, Camera(aspect_ratio=w / h), from_translation((0, 0, cam_z)) @ from_rotation_y(0.1))
+    for m in range(n_meshes):
+        ctr = r.uniform((-spread[0], -spread[1], depth[0]), (spread[0], spread[1], depth[1]), size=(n_tri, 3))
+        pos = (ctr[:, None, :] + r.normal(scale=size, size=(n_tri, 3, 3))).reshape(-1, 3)
+        nrm = r.normal(size=(n_tri * 3, 3))
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        s.meshes.append(Mesh([Submesh(make_vertices(pos, nrm), np.arange(n_tri * 3, dtype=np.uint32))]))
+        s.instances.append((m + 1, from_translation(r.uniform(-0.2, 0.2, 3)) @ from_rotation_x(r.uniform(-0.3, 0.3)), m))
+    for k in range(lights):
+        p = r.uniform((-2, -2, 1), (2, 2, 5))
+        s.lights.append((50 + k, from_translation(p), Light.point(5.0).with_color(Color(*r.uniform(0.2, 1, 3), 2.0))))
+    s.lights.append((60, from_rotation_y(0.4), Light.directional().with_color(Color(1.0, 0.9, 0.8, 1.5))))
+    return s
+
+
+def test_empty_scene():
+    s = SceneDesc("empty", 100, 70, Camera(aspect_ratio=100 / 70), identity())
+    gpu, cpu = render_pair(s)
+    assert_parity(gpu, cpu, min_covered=0)
+    assert (gpu.read_depth() == 1.0).all()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_triangle_soup_with_clipping(seed):
+    # large triangles, many crossing the near plane and the guard band; ragged frame size
+    s = soup_scene(seed, 203, 157)
+    gpu, cpu = render_pair(s)
+    assert_parity(gpu, cpu, min_covered=2000)
+
+
+def test_small_triangle_soup():
+    s = soup_scene(7, 256, 192, n_meshes=4, n_tri=3000, size=0.03, depth=(2.0, 6.0))
+    gpu, cpu = render_pair(s)
+    assert_parity(gpu, cpu, min_covered=1000)
+
+
+def test_c1_sphere_720p():
+    gpu, cpu = render_pair(c1_sphere())
+    assert_parity(gpu, cpu, min_covered=50000)
+
+
+def test_c2_grid_scaled():
+    s = c2_grid_1m(width=640, height=360, scale=0.25)       # 62,500 triangles
+    gpu, cpu = render_pair(s)
+    assert_parity(gpu, cpu, min_covered=640 * 360 // 2)
+
+
+def test_c3_layout_scaled_16_meshes_32_lights():
+    s = c3_grid_10m(width=480, height=270, scale=0.08)      # 16 meshes, 32 lights
+    assert len(s.instances) == 16 and len(s.lights) == 32
+    gpu, cpu = render_pair(s)
+    assert_parity(gpu, cpu, min_covered=480 * 270 // 2)
+
+
+def test_unlit_alpha_and_tone_mapping_off():
+    w, h = 96, 64
+    s = SceneDesc("mat", w, h, Camera(aspect_ratio=w / h), from_translation((0, 0, -3.0)))
+    for tone in (0, 1):
+        pair = []
+        for make in (lambda: VisualServer(w, h, device=0), lambda: oracle_server(w, h)):
+            vs = make()
+            vs.set_tone_mapping(tone)
+            vs.set_camera(s.camera_transform, s.camera)
+            a = vs.asset_server
+            mats = [a.add(Material(base_color=Color(0.2, 0.6, 0.9, 1.0), unlit=True)),
+                    a.add(Material(base_color=Color(1.0, 1.0, 1.0, 0.3))),          # fails the alpha test
+                    a.add(Material(base_color=Color(0.9, 0.4, 0.2, 0.5)))]
+            sphere = uv_sphere_mesh(24, 12, 0.8)
+            for k, m in enumerate(mats):
+                mesh = a.add(Mesh([Submesh(sphere.submeshes[0].vertices, sphere.submeshes[0].indices, m)]))
+                vs.set_mesh_instance(k + 1, from_translation((k - 1.0, 0.0, 0.2 * k)), mesh)
+            vs.set_light(9, from_translation((0, 2, -2)), Light.point(8.0).with_color(Color(1, 1, 1, 2.0)))
+            vs.render()
+            pair.append(vs)
+        assert_parity(pair[0], pair[1], min_covered=500)
+
+
+def test_rerender_after_changes_and_resize():
+    w, h = 160, 120
+    s = soup_scene(11, w, h, n_meshes=2, n_tri=50)
+    gpu, cpu = render_pair(s)
+    assert_parity(gpu, cpu, min_covered=500, hdr=False)
+    for vs in (gpu, cpu):
+        vs.set_render_size((211, 97))
+        vs.set_camera(from_translation((0.2, 0.1, -1.5)), Camera(aspect_ratio=211 / 97))
+        vs.set_light(50, from_translation((0, 0, 2)), Light.point(3.0).with_color(Color(1, 0.2, 0.2, 3.0)))
+        vs.render()
+    assert gpu.read_color_rgba8().shape == (97, 211, 4)
+    assert_parity(gpu, cpu, min_covered=500)
+    for vs in (gpu, cpu):
+        vs.reset_scene()
+        vs.render()
+    assert_parity(gpu, cpu, min_covered=0)
+
+
+def test_full_screen_triangles_many_tiles():
+    # a few triangles far larger than the frame: every tile gets them (64-bit edge-function path)
+    w, h = 512, 320
+    s = SceneDesc("big", w, h, Camera(aspect_ratio=w / h), identity())
+    pos = np.array([(-40, -30, 5), (40, -30, 5), (0, 50, 5), (-30, -30, 3), (30, -35, 9), (5, 45, 4)], dtype=np.float32)
+    s.meshes.append(Mesh([Submesh(make_vertices(pos), np.arange(6, dtype=np.uint32))]))
+    s.instances.append((1, identity(), 0))
+    s.lights.append((5, from_translation((0, 0, 2)), Light.point(10.0).with_color(Color(1, 1, 1, 2.0))))
+    gpu, cpu = render_pair(s)
+    assert_parity(gpu, cpu, min_covered=w * h)
+    st = gpu.frame_stats()
+    assert st["n_bin_entries"] >= 2 * (w // 32) * (h // 32)
+
+
+def test_tile_partition_union_equals_single():
+    s = c2_grid_1m(width=384, height=256, scale=0.1)
+    full, cpu = render_pair(s)
+    ref = full.read_color_rgba8()
+    acc = np.zeros_like(ref)
+    seen = np.zeros(ref.shape[:2], dtype=int)
+    world = 3
+    for rank in range(world):
+        vs = VisualServer(s.width, s.height, device=0)
+        vs.set_tile_partition(rank, world)
+        s.populate(vs)
+        vs.render()
+        img = vs.read_color_rgba8()
+        own = img[..., 3] == 255
+        acc[own] = img[own]
+        seen += own
+    assert (seen == 1).all()
+    assert (acc == ref).all()
