@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Frame-throughput bench of the HIP hot path (contract: see DESIGN.md "Measurement").
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one frame: the reference's per-frame call sequence (set_camera, set_light x L,
+set_mesh_instance x M, render — engine.rs:100-165, visual_server.rs:224-311) over a synthetic
+scene whose meshes are already resident in HBM.  With N > 1 the frame is partitioned sort-first by
+screen tiles, one process per GPU, and the finished tiles are gathered to rank 0 over RCCL and
+de-tiled there (strong scaling: the frame is fixed, the tiles are split).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
+
+WORKLOADS = {
+    # name -> (scene builder name, description)
+    "c1": ("c1_sphere", "C1' UV sphere 16k tri, 1 directional light, 1280x720"),
+    "c2": ("c2_grid_1m", "C2 1M-triangle grid, 8 point lights, 1920x1080"),
+    "c3": ("c3_grid_10m", "C3 10M-triangle scene (16 meshes), 32 point lights, 3840x2160"),
+    "c4": ("c4_layers_50m", "C4 50M triangles in 10 layers, 8 point lights, 7680x4320"),
+    "c5": ("c5_instanced_100m", "C5 1000 instances x 100k triangles, 8 point lights, 3840x2160"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--scale", type=float, default=1.0, help="linear mesh-density scale (debug only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    return ap.parse_args()
+
+
+def fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class FrameDriver:
+    """Per-frame call sequence with pre-built ctypes arguments (keeps the host off the critical path)."""
+
+    def __init__(self, vs, scene):
+        from renderer_amd.types import to_cols_array
+        self.vs, self.api, self.ctx = vs, vs.api, vs._ctx
+        handles = [vs.asset_server.add(m) for m in scene.meshes]
+        mesh_ids = [vs.register_mesh(h) for h in handles]
+        cam = scene.camera
+        self.cam_t = to_cols_array(scene.camera_transform)
+        self.cam_args = (fp(self.cam_t), C.c_float(cam.vfov), C.c_float(cam.aspect_ratio), C.c_float(cam.near),
+                         C.c_float(cam.far))
+        self.keep, self.lights, self.instances = [], [], []
+        for lid, t, light in scene.lights:
+            tt = to_cols_array(t)
+            col = np.asarray(light.color.to_array(), dtype=np.float32)
+            self.keep += [tt, col]
+            self.lights.append((C.c_uint64(lid), fp(tt), fp(col), C.c_uint32(light.kind_id()),
+                                C.c_float(light.radius() or 0.0)))
+        for nid, t, m in scene.instances:
+            tt = to_cols_array(t)
+            self.keep.append(tt)
+            self.instances.append((C.c_uint64(nid), fp(tt), C.c_uint32(mesh_ids[m])))
+
+    def frame(self):
+        api, ctx = self.api, self.ctx
+        rc = api.set_camera(ctx, *self.cam_args)
+        for a in self.lights:
+            rc |= api.set_light(ctx, *a)
+        for a in self.instances:
+            rc |= api.set_mesh_instance(ctx, *a)
+        rc |= api.render(ctx)
+        if rc:
+            raise RuntimeError("frame failed: " + (api.last_error(ctx) or b"").decode())
+
+
+def algorithmic_bytes(stats, n_visible_tris):
+    """Per-frame algorithmic HBM bytes of each kernel (DESIGN.md "Kernels")."""
+    nv, nt = stats["n_vertices"], stats["n_triangles"]
+    nrec, nbin, p = stats["n_setup"], stats["n_bin_entries"], stats["n_pixels"]
+    return {
+        "transform": 12 * nv + 16 * nv,                       # SoA positions in, clip xyzw out
+        "setup": 12 * nt + 16 * nv + 48 * nrec + 4 * nrec,    # indices, each clip position once, records + tile words
+        "bin": 4 * nrec + 4 * nbin,                           # tile words in, bin entries out
+        "raster": 4 * nbin + 48 * nbin + 8 * p,               # entries + records per bin entry, depth|id out
+        "shade": 8 * p + 4 * p + 12 * n_visible_tris + 48 * min(3 * n_visible_tris, nv),   # vis in, rgba8 out, gathers
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from renderer_amd import VisualServer, scenes
+    builder, desc = WORKLOADS[args.workload]
+    kwargs = {"scale": args.scale} if args.workload in ("c2", "c3", "c4") and args.scale != 1.0 else {}
+    scene = getattr(scenes, builder)(**kwargs)
+
+    vs = VisualServer(scene.width, scene.height, device=local_rank)
+    stream = torch.cuda.Stream(device=local_rank)
+    vs.set_stream(stream.cuda_stream)
+    gather_list, tiles = None, None
+    if world > 1:
+        vs.set_tile_partition(rank, world)
+        info = vs.tile_info()
+        counts = [0] * world
+        t = torch.tensor([info["n_owned"]], device="cuda")
+        allc = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allc, t)
+        counts = [int(c.item()) for c in allc]
+        tile_bytes = info["tile_px"] * info["tile_px"] * 4
+        # equal-sized gather buffers: pad every rank to the largest tile count
+        tiles = torch.zeros(max(counts) * tile_bytes, dtype=torch.uint8, device="cuda")
+        vs.set_tiles_output(tiles.data_ptr(), tiles.numel())
+        if rank == 0:
+            gather_list = [torch.empty_like(tiles) for _ in range(world)]
+    driver = FrameDriver(vs, scene)
+
+    def step():
+        with torch.cuda.stream(stream):
+            driver.frame()
+            if world > 1:
+                dist.gather(tiles, gather_list, dst=0)
+                if rank == 0:
+                    for r in range(world):
+                        vs.api.detile(vs._ctx, r, world, C.c_void_p(gather_list[r].data_ptr()))
+
+    def fence():
+        vs.finish()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    vs.mean_timings(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    mean, n_frames = vs.mean_timings()
+    stats = vs.frame_stats()
+    n_tris = scene.n_triangles
+    ms_per_step = elapsed / args.steps * 1e3
+    fps = args.steps / elapsed
+    result = None
+    if rank == 0:
+        ids = vs.read_triangle_ids() if world == 1 else None
+        n_visible = int(np.unique(ids).size - 1) if ids is not None else stats["n_setup"]
+        if ids is not None and not (ids != 0xFFFFFFFF).any():
+            raise SystemExit("bench frame is empty: refusing to report a number")
+        alg = algorithmic_bytes(stats, n_visible)
+        kernels = {}
+        for k in ("transform", "setup", "bin", "raster", "shade"):
+            ms = mean[k + "_ms"]
+            kernels[k] = {"ms": round(ms, 5), "alg_bytes": int(alg[k]),
+                          "gbps": round(alg[k] / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
+        kernels["scan"] = {"ms": round(mean["scan_ms"], 5)}
+        dominant = max(("transform", "setup", "bin", "raster", "shade"), key=lambda k: mean[k + "_ms"])
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("workload") == args.workload and tj.get("n_gpus", 1) == world:
+                    traffic = tj.get("kernels", {}).get(dominant)
+            except Exception:
+                traffic = None
+        achieved = kernels[dominant]["gbps"]
+        result = {
+            "metric": "Mtriangles/s", "value": round(n_tris * fps / 1e6, 2), "unit": "Mtriangles/s",
+            "frames_per_s": round(fps, 2),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": desc if args.scale == 1.0 else f"{desc} (mesh scale {args.scale})",
+                       "triangles": n_tris, "width": scene.width, "height": scene.height,
+                       "lights": len(scene.lights), "draw_items": stats["n_draw_items"],
+                       "partition": "single GPU" if world == 1 else f"sort-first screen tiles over {world} GPUs, RCCL gather to rank 0"},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic},
+            "kernels": kernels,
+            "gpu_frame_ms": round(mean["frame_ms"], 4), "timed_frames": n_frames,
+            "frame_stats": stats,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(scene, desc, args.cpu_threads)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+def cpu_baseline(scene, desc, threads):
+    """The CPU oracle (a restatement, kind "port") on the same workload, bounded to a few frames."""
+    from tests.helpers import oracle_server
+    threads = threads or min(16, os.cpu_count() or 1)
+    cpu = oracle_server(scene.width, scene.height, threads=threads)
+    scene.populate(cpu)
+    cpu.render()                                    # warm-up frame (page faults, allocations)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        cpu.render()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > 10.0 or n >= 5:
+            break
+    return {"value": round(scene.n_triangles * n / dt / 1e6, 3), "unit": "Mtriangles/s", "cores": threads,
+            "kind": "port", "frames_per_s": round(n / dt, 4),
+            "sample": f"{n} frame(s) of the same workload ({desc}) after one warm-up frame, {threads} threads"}
+
+
+if __name__ == "__main__":
+    main()

@@ -172,6 +172,10 @@ int rnd_read_coverage(rnd_ctx* ctx, uint8_t* dst);
 /* id (draw order) of the winning triangle per pixel, RND_NONE where uncovered */
 int rnd_read_triangle_ids(rnd_ctx* ctx, uint32_t* dst);
 int rnd_last_timings(rnd_ctx* ctx, rnd_timings* out);
+/* Mean per-kernel timings over every frame enqueued since the last reset (HIP events recorded on
+ * the context's stream around each kernel; harvested without stalling the frames in flight).
+ * Waits for the frames still in flight.  reset != 0 clears the accumulators afterwards. */
+int rnd_mean_timings(rnd_ctx* ctx, rnd_timings* mean, uint32_t* n_frames, int reset);
 int rnd_frame_stats_get(rnd_ctx* ctx, rnd_frame_stats* out);
 
 /* ---- multi-GPU (no counterpart in the reference, which is single-device;
@@ -186,6 +190,10 @@ int rnd_tile_info(const rnd_ctx* ctx, uint32_t* tile_px, uint32_t* n_owned_tiles
  * n_owned_tiles * tile_px*tile_px*4 bytes, tiles in ascending tile index.  This is what a
  * rank hands to the RCCL gather. */
 int rnd_tiles_device_ptr(rnd_ctx* ctx, void** dev_ptr, uint64_t* n_bytes);
+/* Make this context write its tile-major output into caller-owned device memory (for example a
+ * torch tensor that is then handed to the RCCL gather) instead of its own buffer; n_bytes must be
+ * at least n_owned_tiles * tile_px*tile_px*4.  NULL restores the internal buffer. */
+int rnd_set_tiles_output(rnd_ctx* ctx, void* dev_ptr, uint64_t n_bytes);
 /* On the gathering rank: scatter `src_rank`'s tile-major buffer (device pointer on this
  * context's device) into this context's row-major RGBA8 frame. */
 int rnd_detile(rnd_ctx* ctx, uint32_t src_rank, uint32_t world, const void* dev_tiles);

@@ -95,10 +95,12 @@ SIGNATURES = {
     "read_coverage": (C.c_int, [_P, _P]),
     "read_triangle_ids": (C.c_int, [_P, _P]),
     "last_timings": (C.c_int, [_P, C.POINTER(Timings)]),
+    "mean_timings": (C.c_int, [_P, C.POINTER(Timings), C.POINTER(C.c_uint32), C.c_int]),
     "frame_stats_get": (C.c_int, [_P, C.POINTER(FrameStats)]),
     "set_tile_partition": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "tile_info": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "tiles_device_ptr": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    "set_tiles_output": (C.c_int, [_P, _P, C.c_uint64]),
     "detile": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P]),
     "packed_device_ptr": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     "unpack": (C.c_int, [_P, _P]),
@@ -107,7 +109,7 @@ SIGNATURES = {
 }
 
 # entry points that only make sense with device memory; a host-only library may omit them
-DEVICE_ONLY = {"tiles_device_ptr", "detile", "packed_device_ptr", "unpack", "set_stream",
+DEVICE_ONLY = {"mean_timings", "set_tiles_output", "tiles_device_ptr", "detile", "packed_device_ptr", "unpack", "set_stream",
                "color_device_ptr"}
 
 

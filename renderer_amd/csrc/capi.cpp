@@ -160,6 +160,10 @@ int rnd_last_timings(rnd_ctx* ctx, rnd_timings* out) {
     REQUIRE(ctx, out, "null output");
     return guard(ctx, [&](rnd::VisualServer& v) { *out = v.last_timings(); });
 }
+int rnd_mean_timings(rnd_ctx* ctx, rnd_timings* mean, uint32_t* n_frames, int reset) {
+    REQUIRE(ctx, mean && n_frames, "null output");
+    return guard(ctx, [&](rnd::VisualServer& v) { *mean = v.mean_timings(*n_frames, reset != 0); });
+}
 int rnd_frame_stats_get(rnd_ctx* ctx, rnd_frame_stats* out) {
     REQUIRE(ctx, out, "null output");
     return guard(ctx, [&](rnd::VisualServer& v) { *out = v.frame_stats(); });
@@ -176,6 +180,7 @@ int rnd_tiles_device_ptr(rnd_ctx* ctx, void** p, uint64_t* n) {
     REQUIRE(ctx, p && n, "null output");
     return guard(ctx, [&](rnd::VisualServer& v) { v.tiles_device_ptr(p, n); });
 }
+int rnd_set_tiles_output(rnd_ctx* ctx, void* p, uint64_t n) { return guard(ctx, [&](rnd::VisualServer& v) { v.set_tiles_output(p, n); }); }
 int rnd_detile(rnd_ctx* ctx, uint32_t src_rank, uint32_t world, const void* dev_tiles) {
     return guard(ctx, [&](rnd::VisualServer& v) { v.detile(src_rank, world, dev_tiles); });
 }

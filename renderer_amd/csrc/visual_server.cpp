@@ -45,7 +45,8 @@ VisualServer::VisualServer(uint32_t width, uint32_t height, int device) : device
     if (device < 0 || device >= n_dev) throw Error(RND_ERR_INVALID, "no such HIP device");
     use_device();
     HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-    for (auto& e : ev_) HIP_CHECK(hipEventCreate(&e));
+    for (auto& es : event_sets_)
+        for (auto& e : es.ev) HIP_CHECK(hipEventCreate(&e));
     for (auto& s : staging_) HIP_CHECK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_counters_), sizeof(FrameCounters), hipHostMallocDefault));
     d_counters_.ensure(1);
@@ -72,13 +73,15 @@ VisualServer::~VisualServer() {
     d_records_.release(); d_tilewords_.release(); d_clip_queue_.release(); d_tile_count_.release();
     d_tile_offset_.release(); d_tile_cursor_.release(); d_entries_.release(); d_counters_.release();
     d_launch_order_.release(); d_vis_.release(); d_frame_.release(); d_tiles_.release(); d_packed_.release();
-    d_hdr_.release(); d_detile_list_.release();
+    d_hdr_.release();
+    for (auto& kv : detile_lists_) kv.second.list.release();
     for (auto& s : staging_) {
         if (s.host) (void)hipHostFree(s.host);
         if (s.done) (void)hipEventDestroy(s.done);
     }
     if (h_counters_) (void)hipHostFree(h_counters_);
-    for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
+    for (auto& es : event_sets_)
+        for (auto& e : es.ev) if (e) (void)hipEventDestroy(e);
     if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -89,6 +92,7 @@ void VisualServer::set_render_size(uint32_t w, uint32_t h) {
     if (w == 0 || h == 0 || w > kMaxRenderSize || h > kMaxRenderSize) throw Error(RND_ERR_INVALID, "render size must be in 1..8192");
     finish();
     width_ = w; height_ = h;
+    ext_tiles_ = nullptr; ext_tiles_bytes_ = 0;
     have_frame_ = false;
     rebuild_tiles();   // recreate_render_targets — visual_server.rs:621-662
 }
@@ -143,6 +147,7 @@ void VisualServer::set_tile_partition(uint32_t rank, uint32_t world) {
     if (world == 0 || rank >= world) throw Error(RND_ERR_INVALID, "rank must be < world");
     finish();
     rank_ = rank; world_ = world;
+    ext_tiles_ = nullptr; ext_tiles_bytes_ = 0;
     have_frame_ = false;
     rebuild_tiles();
 }
@@ -380,10 +385,15 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     fb.launch_order = d_launch_order_.ptr; fb.n_owned = n_owned_;
     fb.vis = d_vis_.ptr;
     fb.frame_rgba8 = world_ > 1 ? nullptr : d_frame_.ptr;
-    fb.tiles_rgba8 = world_ > 1 ? d_tiles_.ptr : nullptr;
+    fb.tiles_rgba8 = world_ > 1 ? (ext_tiles_ ? ext_tiles_ : d_tiles_.ptr) : nullptr;
     fb.packed = want_packed_ ? d_packed_.ptr : nullptr;
     fb.hdr = want_hdr ? d_hdr_.ptr : nullptr;
 
+    EventSet& es = event_sets_[event_next_];
+    if (es.pending) harvest(es);
+    last_set_ = (int)event_next_;
+    event_next_ = (event_next_ + 1) % kEventSets;
+    hipEvent_t* ev_ = es.ev;
     HIP_CHECK(hipMemsetAsync(d_counters_.ptr, 0, sizeof(FrameCounters), stream_));
     HIP_CHECK(hipMemsetAsync(d_tile_count_.ptr, 0, n_tiles * 4, stream_));
     HIP_CHECK(hipEventRecord(ev_[0], stream_));
@@ -400,6 +410,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     HIP_CHECK(hipEventRecord(ev_[5], stream_));
     launch_shade(fb, fc, stream_);
     HIP_CHECK(hipEventRecord(ev_[6], stream_));
+    es.pending = true;
     HIP_CHECK(hipMemcpyAsync(h_counters_, d_counters_.ptr, sizeof(FrameCounters), hipMemcpyDeviceToHost, stream_));
     HIP_CHECK(hipGetLastError());
     frame_pending_ = true;
@@ -437,13 +448,46 @@ void VisualServer::finish() {
         px += (uint64_t)std::min(kTile, width_ - tx * kTile) * std::min(kTile, height_ - ty * kTile);
     }
     stats_.n_pixels = px;
+    for (auto& es : event_sets_)
+        if (es.pending) harvest(es);
+    have_frame_ = true;
+}
+
+// Reads one completed frame's events into timings_ and the running sums.
+void VisualServer::harvest(EventSet& es) {
+    HIP_CHECK(hipEventSynchronize(es.ev[kEventsPerSet - 1]));
     float ms[6] = {};
-    for (int k = 0; k < 6; ++k) HIP_CHECK(hipEventElapsedTime(&ms[k], ev_[k], ev_[k + 1]));
+    for (int k = 0; k < 6; ++k) HIP_CHECK(hipEventElapsedTime(&ms[k], es.ev[k], es.ev[k + 1]));
     timings_ = rnd_timings{};
     timings_.transform_ms = ms[0]; timings_.setup_ms = ms[1]; timings_.scan_ms = ms[2]; timings_.bin_ms = ms[3];
     timings_.raster_ms = ms[4]; timings_.shade_ms = ms[5];
-    HIP_CHECK(hipEventElapsedTime(&timings_.frame_ms, ev_[0], ev_[6]));
-    have_frame_ = true;
+    HIP_CHECK(hipEventElapsedTime(&timings_.frame_ms, es.ev[0], es.ev[6]));
+    for (int k = 0; k < 6; ++k) timing_sum_[k] += ms[k];
+    timing_sum_[6] += timings_.frame_ms;
+    timing_frames_ += 1;
+    es.pending = false;
+}
+
+rnd_timings VisualServer::mean_timings(uint32_t& n_frames, bool reset) {
+    finish();
+    rnd_timings m{};
+    n_frames = timing_frames_;
+    if (timing_frames_) {
+        const double inv = 1.0 / timing_frames_;
+        m.transform_ms = (float)(timing_sum_[0] * inv); m.setup_ms = (float)(timing_sum_[1] * inv);
+        m.scan_ms = (float)(timing_sum_[2] * inv); m.bin_ms = (float)(timing_sum_[3] * inv);
+        m.raster_ms = (float)(timing_sum_[4] * inv); m.shade_ms = (float)(timing_sum_[5] * inv);
+        m.frame_ms = (float)(timing_sum_[6] * inv);
+    }
+    if (reset) { for (double& v : timing_sum_) v = 0.0; timing_frames_ = 0; }
+    return m;
+}
+
+void VisualServer::set_tiles_output(void* dev_ptr, uint64_t bytes) {
+    finish();
+    if (dev_ptr && bytes < (uint64_t)n_owned_ * kTilePixels * 4) throw Error(RND_ERR_INVALID, "tile output buffer too small");
+    ext_tiles_ = static_cast<uint8_t*>(dev_ptr);
+    ext_tiles_bytes_ = bytes;
 }
 
 void VisualServer::need_frame() const {
@@ -456,7 +500,7 @@ void VisualServer::read_color_rgba8(uint8_t* dst) {
     finish(); need_frame(); use_device();
     if (world_ > 1) {   // a partitioned context holds only its tiles: assemble them over a cleared frame
         HIP_CHECK(hipMemsetAsync(d_frame_.ptr, 0, (size_t)width_ * height_ * 4, stream_));
-        detile(rank_, world_, d_tiles_.ptr);
+        detile(rank_, world_, ext_tiles_ ? ext_tiles_ : d_tiles_.ptr);
     }
     HIP_CHECK(hipMemcpyAsync(dst, d_frame_.ptr, (size_t)width_ * height_ * 4, hipMemcpyDeviceToHost, stream_));
     HIP_CHECK(hipStreamSynchronize(stream_));
@@ -504,23 +548,29 @@ rnd_frame_stats VisualServer::frame_stats() { finish(); need_frame(); return sta
 void VisualServer::tiles_device_ptr(void** p, uint64_t* bytes) {
     if (world_ <= 1) throw Error(RND_ERR_INVALID, "no tile partition set");
     need_frame();
-    *p = d_tiles_.ptr; *bytes = (uint64_t)n_owned_ * kTilePixels * 4;
+    *p = ext_tiles_ ? ext_tiles_ : d_tiles_.ptr; *bytes = (uint64_t)n_owned_ * kTilePixels * 4;
 }
 
 void VisualServer::detile(uint32_t src_rank, uint32_t world, const void* dev_tiles) {
     if (!dev_tiles || world == 0 || src_rank >= world) throw Error(RND_ERR_INVALID, "bad detile arguments");
     use_device();
-    std::vector<uint32_t> list = owned_tiles(src_rank, world);
-    if (list.empty()) return;
-    d_detile_list_.ensure(list.size());
-    // the list is consumed by the kernel below on the same stream; a pageable copy is synchronous
-    HIP_CHECK(hipMemcpyAsync(d_detile_list_.ptr, list.data(), list.size() * 4, hipMemcpyHostToDevice, stream_));
-    HIP_CHECK(hipStreamSynchronize(stream_));
+    // tile lists per (rank, world) are built once and stay on the device; the launch is asynchronous
+    const uint64_t key = ((uint64_t)world << 32) | src_rank;
+    auto it = detile_lists_.find(key);
+    if (it == detile_lists_.end() || it->second.tiles_x != tiles_x_ || it->second.tiles_y != tiles_y_) {
+        if (it != detile_lists_.end()) { it->second.list.release(); detile_lists_.erase(it); }
+        std::vector<uint32_t> list = owned_tiles(src_rank, world);
+        DetileList dl;
+        dl.tiles_x = tiles_x_; dl.tiles_y = tiles_y_; dl.n = (uint32_t)list.size();
+        dl.list.ensure(std::max<size_t>(list.size(), 1));
+        if (!list.empty()) HIP_CHECK(hipMemcpy(dl.list.ptr, list.data(), list.size() * 4, hipMemcpyHostToDevice));
+        it = detile_lists_.emplace(key, dl).first;
+    }
+    if (!it->second.n) return;
     FrameConst fc = fc_;
     fc.width = width_; fc.height = height_; fc.tiles_x = tiles_x_; fc.tiles_y = tiles_y_;
-    launch_detile(static_cast<const uint8_t*>(dev_tiles), d_detile_list_.ptr, (uint32_t)list.size(), fc, d_frame_.ptr, stream_);
+    launch_detile(static_cast<const uint8_t*>(dev_tiles), it->second.list.ptr, it->second.n, fc, d_frame_.ptr, stream_);
     HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
 void VisualServer::packed_device_ptr(void** p, uint64_t* bytes) {

@@ -104,12 +104,14 @@ public:
     void read_color_hdr(float* dst);
     void read_planes(float* depth, uint32_t* ids, uint8_t* coverage);
     rnd_timings last_timings();
+    rnd_timings mean_timings(uint32_t& n_frames, bool reset);
     rnd_frame_stats frame_stats();
 
     // multi-GPU
     void set_tile_partition(uint32_t rank, uint32_t world);
     void tile_info(uint32_t& tile_px, uint32_t& n_owned, uint32_t& n_total) const;
     void tiles_device_ptr(void** p, uint64_t* bytes);
+    void set_tiles_output(void* dev_ptr, uint64_t bytes);
     void detile(uint32_t src_rank, uint32_t world, const void* dev_tiles);
     void packed_device_ptr(void** p, uint64_t* bytes);
     void unpack(const void* dev_packed);
@@ -139,7 +141,20 @@ private:
 
     hipStream_t stream_ = nullptr;
     bool own_stream_ = true;
-    hipEvent_t ev_[9] = {};
+    // ring of per-frame event sets, so kernel timings can be harvested without a per-frame sync
+    static constexpr int kEventSets = 16, kEventsPerSet = 7;
+    struct EventSet {
+        hipEvent_t ev[kEventsPerSet] = {};
+        bool pending = false;
+    };
+    EventSet event_sets_[kEventSets];
+    uint32_t event_next_ = 0;
+    int last_set_ = -1;
+    double timing_sum_[8] = {};
+    uint32_t timing_frames_ = 0;
+    void harvest(EventSet& s);
+    uint8_t* ext_tiles_ = nullptr;
+    uint64_t ext_tiles_bytes_ = 0;
 
     // RenderScene — visual_server.rs:896-905 (insertion-ordered instead of HashMap order)
     std::unordered_map<uint32_t, RenderMesh> meshes_;
@@ -167,7 +182,11 @@ private:
     DeviceBuffer<uint8_t> d_frame_, d_tiles_;
     DeviceBuffer<uint64_t> d_packed_;
     DeviceBuffer<float> d_hdr_;
-    DeviceBuffer<uint32_t> d_detile_list_;
+    struct DetileList {
+        DeviceBuffer<uint32_t> list;
+        uint32_t n = 0, tiles_x = 0, tiles_y = 0;
+    };
+    std::unordered_map<uint64_t, DetileList> detile_lists_;
     Capacities cap_{0, 0, 0};
 
     // pinned staging ring for the per-frame tables

@@ -216,6 +216,11 @@ class VisualServer:
         self._check(self.api.last_timings(self._ctx, C.byref(t)))
         return t.as_dict()
 
+    def mean_timings(self, reset=False):
+        t, n = Timings(), C.c_uint32()
+        self._check(self.api.mean_timings(self._ctx, C.byref(t), C.byref(n), int(reset)))
+        return t.as_dict(), n.value
+
     def frame_stats(self):
         s = FrameStats()
         self._check(self.api.frame_stats_get(self._ctx, C.byref(s)))
@@ -243,6 +248,9 @@ class VisualServer:
 
     def color_device_ptr(self):
         return self._devptr(self.api.color_device_ptr)
+
+    def set_tiles_output(self, dev_ptr, n_bytes):
+        self._check(self.api.set_tiles_output(self._ctx, C.c_void_p(dev_ptr), int(n_bytes)))
 
     def detile(self, src_rank, world, dev_ptr):
         self._check(self.api.detile(self._ctx, int(src_rank), int(world), C.c_void_p(dev_ptr)))
