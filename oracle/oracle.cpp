@@ -229,8 +229,8 @@ static inline void barycentrics(const V4& c0, const V4& c1, const V4& c2, uint32
     double e0 = ((y1 * w2 - w1 * y2) * xn + (w1 * x2 - x1 * w2) * yn) + (x1 * y2 - y1 * x2);
     double e1 = ((y2 * w0 - w2 * y0) * xn + (w2 * x0 - x2 * w0) * yn) + (x2 * y0 - y2 * x0);
     double e2 = ((y0 * w1 - w0 * y1) * xn + (w0 * x1 - x0 * w1) * yn) + (x0 * y1 - y0 * x1);
-    double s = (e0 + e1) + e2;
-    double b0 = e0 / s, b1 = e1 / s, b2 = e2 / s;
+    double inv_s = 1.0 / ((e0 + e1) + e2);
+    double b0 = e0 * inv_s, b1 = e1 * inv_s, b2 = e2 * inv_s;
     if (!(std::isfinite(b0) && std::isfinite(b1) && std::isfinite(b2))) { b0 = 1.0; b1 = 0.0; b2 = 0.0; }
     b[0] = (float)b0; b[1] = (float)b1; b[2] = (float)b2;
 }

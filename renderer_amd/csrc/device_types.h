@@ -52,7 +52,8 @@ struct GpuLight {
     uint32_t kind;
     float color[4];     // rgb + intensity
     int32_t shadow_index;   // index of this light's cascade set, -1 = none
-    uint32_t pad[3];
+    float inv_radius;       // 1 / radius (point lights)
+    uint32_t pad[2];
 };
 
 // Per-frame constants passed by value to the kernels.
@@ -82,14 +83,18 @@ static_assert(sizeof(SetupRecord) == 48, "SetupRecord is 3 x 16 bytes");
 
 // Device-side counters of one frame.
 struct FrameCounters {
-    uint32_t n_records;        // setup records written
+    uint32_t n_records;        // setup records written by the clipper (after the deterministic slots)
     uint32_t n_clip;           // triangles queued for the clipper
     uint32_t n_entries;        // bin entries (sum of tile counts)
     uint32_t overflow;         // bit 0 records, bit 1 clip queue, bit 2 entries
+    uint32_t n_valid;          // valid setup records (statistics)
+    uint32_t pad[3];
 };
 
 struct Capacities {
-    uint32_t records, clip_queue, entries;
+    uint32_t records;       // slots in the record stream: setup_slots + room for the clipper's records
+    uint32_t clip_queue, entries;
+    uint32_t setup_slots;   // deterministic slots of k_setup: n_tris rounded up to its chunk size
 };
 
 }  // namespace rnd

@@ -37,6 +37,9 @@ struct FrameBuffers {
     float* hdr;                     // row-major f32 rgb (may be null; read-back only)
 };
 
+// slots k_setup addresses for n_tris triangles (its workgroups own fixed chunks of the record stream)
+uint32_t setup_slots_for(uint32_t n_tris);
+
 void launch_transform(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream);
 void launch_setup(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream);
 void launch_clip(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream);

@@ -19,6 +19,8 @@
 
 namespace rnd {
 
+uint32_t setup_slots_for(uint32_t n_tris) { return (uint32_t)(((uint64_t)n_tris + 2047u) / 2048u * 2048u); }
+
 // ------------------------------------------------------------------------------------------
 // helpers
 // ------------------------------------------------------------------------------------------
@@ -185,78 +187,89 @@ __device__ __forceinline__ void bin_wave(bool emit, const TileRect& t, uint32_t 
     }
 }
 
+// Slots of the record stream are deterministic: workgroup b owns slots [b*kSetupChunk,
+// (b+1)*kSetupChunk) and fills them densely from the front with a ballot + LDS prefix over its
+// waves; the unused tail gets an invalid tile word.  No global counter sits on this path (one
+// word takes ~88 atomics/us on MI355X: 10M triangles / 64 lanes on one counter cost 1.4 ms here).
+constexpr uint32_t kSetupChunk = 2048;
+constexpr uint32_t kInvalidTileword = 0xFFFFFFFFu;
+
 __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, FrameConst fc, Capacities cap) {
-    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t lane = lane_id();
-    bool emit = false, need_clip = false;
-    SetupRecord rec;
-    TileRect tr{0, 0, 0, 0};
-    if (gid < fc.n_tris) {
-        uint32_t it = find_item(fb.tri_bases, fc.n_items, gid);
-        const DrawItem& d = fb.items[it];
-        if (!(d.flags & kItemSkip)) {
-            uint32_t t = gid - d.tri_base;
-            const uint32_t* ix = d.indices + 3ull * t;
-            float4 c0 = fb.clip[d.vert_base + ix[0]];
-            float4 c1 = fb.clip[d.vert_base + ix[1]];
-            float4 c2 = fb.clip[d.vert_base + ix[2]];
-            bool finite = isfinite(c0.x) && isfinite(c0.y) && isfinite(c0.z) && isfinite(c0.w) &&
-                          isfinite(c1.x) && isfinite(c1.y) && isfinite(c1.z) && isfinite(c1.w) &&
-                          isfinite(c2.x) && isfinite(c2.y) && isfinite(c2.z) && isfinite(c2.w);
-            // trivial reject against the view volume
-            bool out = (c0.x < -c0.w && c1.x < -c1.w && c2.x < -c2.w) || (c0.x > c0.w && c1.x > c1.w && c2.x > c2.w) ||
-                       (c0.y < -c0.w && c1.y < -c1.w && c2.y < -c2.w) || (c0.y > c0.w && c1.y > c1.w && c2.y > c2.w) ||
-                       (c0.z < 0.0f && c1.z < 0.0f && c2.z < 0.0f) || (c0.z > c0.w && c1.z > c1.w && c2.z > c2.w);
-            if (finite && !out) {
-                float g0 = kGuardBand * c0.w, g1 = kGuardBand * c1.w, g2 = kGuardBand * c2.w;
-                need_clip = (c0.z < 0.0f) | (c0.z > c0.w) | (c0.x < -g0) | (c0.x > g0) | (c0.y < -g0) | (c0.y > g0) |
-                            (c1.z < 0.0f) | (c1.z > c1.w) | (c1.x < -g1) | (c1.x > g1) | (c1.y < -g1) | (c1.y > g1) |
-                            (c2.z < 0.0f) | (c2.z > c2.w) | (c2.x < -g2) | (c2.x > g2) | (c2.y < -g2) | (c2.y > g2);
-                if (!need_clip) {
-                    float half_w = 0.5f * (float)fc.width, half_h = 0.5f * (float)fc.height;
-                    Snapped s0, s1, s2;
-                    bool ok0 = snap_vertex(c0.x, c0.y, c0.z, c0.w, half_w, half_h, s0);
-                    bool ok1 = snap_vertex(c1.x, c1.y, c1.z, c1.w, half_w, half_h, s1);
-                    bool ok2 = snap_vertex(c2.x, c2.y, c2.z, c2.w, half_w, half_h, s2);
-                    if (ok0 && ok1 && ok2) emit = make_record(s0, s1, s2, gid, fc, rec, tr) && any_owned(tr, fc);
+    __shared__ uint32_t s_wave_cnt[2][4];
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t chunk_base = blockIdx.x * kSetupChunk;
+    const float half_w = 0.5f * (float)fc.width, half_h = 0.5f * (float)fc.height;
+    uint32_t running = 0;
+    for (uint32_t iter = 0; iter < kSetupChunk / 256u; ++iter) {
+        const uint32_t gid = chunk_base + iter * 256u + threadIdx.x;
+        bool emit = false, need_clip = false;
+        SetupRecord rec;
+        TileRect tr{0, 0, 0, 0};
+        if (gid < fc.n_tris) {
+            uint32_t it = find_item(fb.tri_bases, fc.n_items, gid);
+            const DrawItem& d = fb.items[it];
+            if (!(d.flags & kItemSkip)) {
+                uint32_t t = gid - d.tri_base;
+                const uint32_t* ix = d.indices + 3ull * t;
+                float4 c0 = fb.clip[d.vert_base + ix[0]];
+                float4 c1 = fb.clip[d.vert_base + ix[1]];
+                float4 c2 = fb.clip[d.vert_base + ix[2]];
+                bool finite = isfinite(c0.x) && isfinite(c0.y) && isfinite(c0.z) && isfinite(c0.w) &&
+                              isfinite(c1.x) && isfinite(c1.y) && isfinite(c1.z) && isfinite(c1.w) &&
+                              isfinite(c2.x) && isfinite(c2.y) && isfinite(c2.z) && isfinite(c2.w);
+                // trivial reject against the view volume
+                bool out = (c0.x < -c0.w && c1.x < -c1.w && c2.x < -c2.w) || (c0.x > c0.w && c1.x > c1.w && c2.x > c2.w) ||
+                           (c0.y < -c0.w && c1.y < -c1.w && c2.y < -c2.w) || (c0.y > c0.w && c1.y > c1.w && c2.y > c2.w) ||
+                           (c0.z < 0.0f && c1.z < 0.0f && c2.z < 0.0f) || (c0.z > c0.w && c1.z > c1.w && c2.z > c2.w);
+                if (finite && !out) {
+                    float g0 = kGuardBand * c0.w, g1 = kGuardBand * c1.w, g2 = kGuardBand * c2.w;
+                    need_clip = (c0.z < 0.0f) | (c0.z > c0.w) | (c0.x < -g0) | (c0.x > g0) | (c0.y < -g0) | (c0.y > g0) |
+                                (c1.z < 0.0f) | (c1.z > c1.w) | (c1.x < -g1) | (c1.x > g1) | (c1.y < -g1) | (c1.y > g1) |
+                                (c2.z < 0.0f) | (c2.z > c2.w) | (c2.x < -g2) | (c2.x > g2) | (c2.y < -g2) | (c2.y > g2);
+                    if (!need_clip) {
+                        Snapped s0, s1, s2;
+                        bool ok0 = snap_vertex(c0.x, c0.y, c0.z, c0.w, half_w, half_h, s0);
+                        bool ok1 = snap_vertex(c1.x, c1.y, c1.z, c1.w, half_w, half_h, s1);
+                        bool ok2 = snap_vertex(c2.x, c2.y, c2.z, c2.w, half_w, half_h, s2);
+                        if (ok0 && ok1 && ok2) emit = make_record(s0, s1, s2, gid, fc, rec, tr) && any_owned(tr, fc);
+                    }
                 }
             }
         }
-    }
-    // queue the triangles that need the clipper (wave-compacted)
-    unsigned long long cm = __ballot(need_clip);
-    if (cm) {
-        int leader = __ffsll((long long)cm) - 1;
-        uint32_t base = 0;
-        if (lane == (uint32_t)leader) base = atomicAdd(&fb.counters->n_clip, (uint32_t)__popcll(cm));
-        base = __shfl(base, leader);
-        if (need_clip) {
-            uint32_t q = base + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull));
-            if (q < cap.clip_queue) fb.clip_queue[q] = gid; else atomicOr(&fb.counters->overflow, 2u);
-        }
-    }
-    // wave-compacted record stream: one atomic per wave
-    unsigned long long em = __ballot(emit);
-    uint32_t slot = 0;
-    if (em) {
-        int leader = __ffsll((long long)em) - 1;
-        uint32_t base = 0;
-        if (lane == (uint32_t)leader) base = atomicAdd(&fb.counters->n_records, (uint32_t)__popcll(em));
-        base = __shfl(base, leader);
-        slot = base + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
-        if (emit) {
-            if (slot < cap.records) {
-                float4* dst = reinterpret_cast<float4*>(fb.records + slot);
-                const float4* src = reinterpret_cast<const float4*>(&rec);
-                dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
-                fb.tilewords[slot] = pack_tileword(tr);
-            } else {
-                atomicOr(&fb.counters->overflow, 1u);
-                emit = false;
+        // queue the triangles that need the clipper (wave-compacted, rare)
+        unsigned long long cm = __ballot(need_clip);
+        if (cm) {
+            int leader = __ffsll((long long)cm) - 1;
+            uint32_t base = 0;
+            if (lane == (uint32_t)leader) base = atomicAdd(&fb.counters->n_clip, (uint32_t)__popcll(cm));
+            base = __shfl(base, leader);
+            if (need_clip) {
+                uint32_t q = base + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull));
+                if (q < cap.clip_queue) fb.clip_queue[q] = gid; else atomicOr(&fb.counters->overflow, 2u);
             }
         }
+        // workgroup-compacted record stream
+        unsigned long long em = __ballot(emit);
+        if (lane == 0) s_wave_cnt[iter & 1u][wave] = (uint32_t)__popcll(em);
+        __syncthreads();
+        uint32_t wave_base = 0, total = 0;
+        for (uint32_t w = 0; w < 4; ++w) {
+            uint32_t c = s_wave_cnt[iter & 1u][w];
+            if (w < wave) wave_base += c;
+            total += c;
+        }
+        const uint32_t slot = chunk_base + running + wave_base + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
+        running += total;
+        if (emit) {
+            float4* dst = reinterpret_cast<float4*>(fb.records + slot);
+            const float4* src = reinterpret_cast<const float4*>(&rec);
+            dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+            fb.tilewords[slot] = pack_tileword(tr);
+        }
+        bin_wave<0>(emit, tr, slot, fc, fb.tile_count, nullptr, nullptr, 0);
     }
-    bin_wave<0>(emit, tr, slot, fc, fb.tile_count, nullptr, nullptr, 0);
+    for (uint32_t k = running + threadIdx.x; k < kSetupChunk; k += 256u) fb.tilewords[chunk_base + k] = kInvalidTileword;
+    if (threadIdx.x == 0 && running) atomicAdd(&fb.counters->n_valid, running);
 }
 
 // --- clipper (rare path): near, far and the four guard-band planes, then a fan -------------
@@ -321,8 +334,9 @@ __global__ __launch_bounds__(256) void k_clip(FrameBuffers fb, FrameConst fc, Ca
             SetupRecord rec;
             TileRect tr;
             if (!make_record(s[0], s[k], s[k + 1], gid, fc, rec, tr) || !any_owned(tr, fc)) continue;
-            uint32_t slot = atomicAdd(&fb.counters->n_records, 1u);
+            uint32_t slot = cap.setup_slots + atomicAdd(&fb.counters->n_records, 1u);
             if (slot >= cap.records) { atomicOr(&fb.counters->overflow, 1u); continue; }
+            atomicAdd(&fb.counters->n_valid, 1u);
             fb.records[slot] = rec;
             fb.tilewords[slot] = pack_tileword(tr);
             for (uint32_t ty = tr.ty0; ty <= tr.ty1; ++ty)
@@ -369,13 +383,14 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(FrameBuffers fb, FrameConst
 
 // --- K2b: scatter record slots into the bins ---------------------------------------------
 __global__ __launch_bounds__(256) void k_bin_fill(FrameBuffers fb, FrameConst fc, Capacities cap) {
-    const uint32_t n = min(fb.counters->n_records, cap.records);
+    const uint32_t n = min(cap.setup_slots + fb.counters->n_records, cap.records);
     for (uint32_t r0 = blockIdx.x * 256u; r0 < n; r0 += gridDim.x * 256u) {
         uint32_t r = r0 + threadIdx.x;
         bool valid = r < n;
         TileRect t{0, 0, 0, 0};
         if (valid) {
             uint32_t w = fb.tilewords[r];
+            valid = w != kInvalidTileword;
             t.tx0 = w & 255u; t.ty0 = (w >> 8) & 255u;
             t.tx1 = t.tx0 + ((w >> 16) & 255u); t.ty1 = t.ty0 + (w >> 24);
         }
@@ -529,27 +544,67 @@ __device__ __forceinline__ uint32_t srgb8(float lin) {
     return (uint32_t)min(max(v, 0), 255);
 }
 
-__device__ __forceinline__ void shade_pixel(const FrameBuffers& fb, const FrameConst& fc,
-                                            const GpuLight* __restrict__ lights, uint32_t id, uint32_t i,
-                                            uint32_t j, float hdr[3]) {
+// Colour parity is a tolerance (<= 1/255 on >= 99.9 % of pixels), so the light loop uses the
+// hardware reciprocal / reciprocal-square-root / exp2 / log2 (v_rcp_f32, v_rsq_f32: 1 ulp) instead
+// of the correctly rounded sequences; build with -DRND_FAST_SHADE=0 for the bit-exact variant.
+#ifndef RND_FAST_SHADE
+#define RND_FAST_SHADE 1
+#endif
+__device__ __forceinline__ float rcp_f(float x) {
+#if RND_FAST_SHADE
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+__device__ __forceinline__ float rsqrt_f(float x) {
+#if RND_FAST_SHADE
+    return __builtin_amdgcn_rsqf(x);
+#else
+    return 1.0f / sqrtf(x);
+#endif
+}
+__device__ __forceinline__ uint32_t srgb8_f(float lin) {
+#if RND_FAST_SHADE
+    float x = fminf(fmaxf(lin, 0.0f), 1.0f);
+    float y = (x <= 0.0031308f) ? 12.92f * x : 1.055f * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (1.0f / 2.4f)) - 0.055f;
+    int v = (int)(y * 255.0f + 0.5f);
+    return (uint32_t)min(max(v, 0), 255);
+#else
+    return srgb8(lin);
+#endif
+}
+
+struct PixelInputs {
+    float fx, fy, fz;       // world position (frag_pos)
+    float Nx, Ny, Nz;       // normalized normal
+    float Vx, Vy, Vz;       // normalized fragment -> camera
+    float br, bg, bb;       // base colour
+    float cr, cg, cb;       // accumulated colour
+    bool lit;               // takes part in the light loop
+};
+
+// vs_main outputs re-derived for the winning triangle of one pixel, and the ambient term
+__device__ __forceinline__ void prepare_pixel(const FrameBuffers& fb, const FrameConst& fc, uint32_t id, uint32_t i,
+                                              uint32_t j, PixelInputs& o) {
     uint32_t it = find_item(fb.tri_bases, fc.n_items, id);
     const DrawItem& d = fb.items[it];
     uint32_t t = id - d.tri_base;
     const uint32_t* ix = d.indices + 3ull * t;
     uint32_t i0 = ix[0], i1 = ix[1], i2 = ix[2];
     float4 c0 = fb.clip[d.vert_base + i0], c1 = fb.clip[d.vert_base + i1], c2 = fb.clip[d.vert_base + i2];
-    // barycentrics
+    // perspective-correct barycentrics: 2D homogeneous edge functions in f64
     double x0 = c0.x, y0 = c0.y, w0 = c0.w, x1 = c1.x, y1 = c1.y, w1 = c1.w, x2 = c2.x, y2 = c2.y, w2 = c2.w;
     double xn = (2.0 * ((double)i + 0.5)) / (double)fc.width - 1.0;
     double yn = 1.0 - (2.0 * ((double)j + 0.5)) / (double)fc.height;
     double e0 = ((y1 * w2 - w1 * y2) * xn + (w1 * x2 - x1 * w2) * yn) + (x1 * y2 - y1 * x2);
     double e1 = ((y2 * w0 - w2 * y0) * xn + (w2 * x0 - x2 * w0) * yn) + (x2 * y0 - y2 * x0);
     double e2 = ((y0 * w1 - w0 * y1) * xn + (w0 * x1 - x0 * w1) * yn) + (x0 * y1 - y0 * x1);
-    double s = (e0 + e1) + e2;
-    double d0 = e0 / s, d1 = e1 / s, d2 = e2 / s;
+    double inv_s = 1.0 / ((e0 + e1) + e2);
+    double d0 = e0 * inv_s, d1 = e1 * inv_s, d2 = e2 * inv_s;
     if (!(isfinite(d0) && isfinite(d1) && isfinite(d2))) { d0 = 1.0; d1 = 0.0; d2 = 0.0; }
     const float b0 = (float)d0, b1 = (float)d1, b2 = (float)d2;
-    // attributes, interpolated in object space
+    // attributes, interpolated in object space and transformed once
     const rnd_vertex va = d.verts[i0], vb = d.verts[i1], vc = d.verts[i2];
     float px = (b0 * va.position[0] + b1 * vb.position[0]) + b2 * vc.position[0];
     float py = (b0 * va.position[1] + b1 * vb.position[1]) + b2 * vc.position[1];
@@ -558,92 +613,183 @@ __device__ __forceinline__ void shade_pixel(const FrameBuffers& fb, const FrameC
     float ny = (b0 * va.normal[1] + b1 * vb.normal[1]) + b2 * vc.normal[1];
     float nz = (b0 * va.normal[2] + b1 * vb.normal[2]) + b2 * vc.normal[2];
     const float* m = d.world;
-    float fx = ((m[0] * px + m[4] * py) + m[8] * pz) + m[12];
-    float fy = ((m[1] * px + m[5] * py) + m[9] * pz) + m[13];
-    float fz = ((m[2] * px + m[6] * py) + m[10] * pz) + m[14];
+    o.fx = ((m[0] * px + m[4] * py) + m[8] * pz) + m[12];
+    o.fy = ((m[1] * px + m[5] * py) + m[9] * pz) + m[13];
+    o.fz = ((m[2] * px + m[6] * py) + m[10] * pz) + m[14];
     const float* q = d.nrm;
     float gx = (q[0] * nx + q[4] * ny) + q[8] * nz;
     float gy = (q[1] * nx + q[5] * ny) + q[9] * nz;
     float gz = (q[2] * nx + q[6] * ny) + q[10] * nz;
     // base colour (untextured: the 1x1 white texture)
-    float br = d.base_color[0] * 1.0f, bg = d.base_color[1] * 1.0f, bb = d.base_color[2] * 1.0f;
-    float cr = br, cg = bg, cb = bb;
-    if (!(d.flags & kItemUnlit)) {
+    o.br = d.base_color[0] * 1.0f; o.bg = d.base_color[1] * 1.0f; o.bb = d.base_color[2] * 1.0f;
+    o.lit = !(d.flags & kItemUnlit);
+    if (o.lit) {
         float ar = fc.ambient[0] * fc.ambient[3], ag = fc.ambient[1] * fc.ambient[3], ab = fc.ambient[2] * fc.ambient[3];
-        cr = br * ar; cg = bg * ag; cb = bb * ab;
-        float inv_n = 1.0f / sqrtf(dot3(gx, gy, gz, gx, gy, gz));
-        float Nx = gx * inv_n, Ny = gy * inv_n, Nz = gz * inv_n;
-        float vx = fc.cam_pos[0] - fx, vy = fc.cam_pos[1] - fy, vz = fc.cam_pos[2] - fz;
-        float inv_v = 1.0f / sqrtf(dot3(vx, vy, vz, vx, vy, vz));
-        float Vx = vx * inv_v, Vy = vy * inv_v, Vz = vz * inv_v;
-        for (uint32_t l = 0; l < fc.n_lights; ++l) {
-            const GpuLight& L = lights[l];
-            float dx, dy, dz, intensity;
-            if (L.kind == RND_LIGHT_DIRECTIONAL) {
-                dx = L.dir[0]; dy = L.dir[1]; dz = L.dir[2];
-                float occlusion = 0.0f;
-                intensity = L.color[3] * (1.0f - occlusion);
-            } else {
-                float ox = fx - L.pos[0], oy = fy - L.pos[1], oz = fz - L.pos[2];
-                float dist = sqrtf(dot3(ox, oy, oz, ox, oy, oz));
-                if (dist > L.radius) continue;
-                float inv_d = 1.0f / dist;
-                dx = ox * inv_d; dy = oy * inv_d; dz = oz * inv_d;
-                float lin = fminf(fmaxf((L.radius - dist) / L.radius, 0.0f), 1.0f);
-                float att = (lin * lin) * (3.0f - 2.0f * lin);
-                intensity = L.color[3] * att;
-            }
-            float tx = -dx, ty = -dy, tz = -dz;
-            float diff = fmaxf(dot3(Nx, Ny, Nz, tx, ty, tz), 0.0f);
-            float lr = L.color[0] * intensity, lg = L.color[1] * intensity, lb = L.color[2] * intensity;
-            float hx = tx + Vx, hy = ty + Vy, hz = tz + Vz;
-            float inv_h = 1.0f / sqrtf(dot3(hx, hy, hz, hx, hy, hz));
-            hx *= inv_h; hy *= inv_h; hz *= inv_h;
-            float sp = fmaxf(dot3(Nx, Ny, Nz, hx, hy, hz), 0.0f);
-            float s2 = sp * sp, s4 = s2 * s2, s8 = s4 * s4;
-            cr = cr + br * (lr * diff + lr * s8);
-            cg = cg + bg * (lg * diff + lg * s8);
-            cb = cb + bb * (lb * diff + lb * s8);
-        }
+        o.cr = o.br * ar; o.cg = o.bg * ag; o.cb = o.bb * ab;
+        float inv_n = rsqrt_f(dot3(gx, gy, gz, gx, gy, gz));
+        o.Nx = gx * inv_n; o.Ny = gy * inv_n; o.Nz = gz * inv_n;
+        float vx = fc.cam_pos[0] - o.fx, vy = fc.cam_pos[1] - o.fy, vz = fc.cam_pos[2] - o.fz;
+        float inv_v = rsqrt_f(dot3(vx, vy, vz, vx, vy, vz));
+        o.Vx = vx * inv_v; o.Vy = vy * inv_v; o.Vz = vz * inv_v;
+    } else {
+        o.cr = o.br; o.cg = o.bg; o.cb = o.bb;
+        o.Nx = o.Ny = o.Nz = o.Vx = o.Vy = o.Vz = 0.0f;
     }
-    hdr[0] = round_f16(cr); hdr[1] = round_f16(cg); hdr[2] = round_f16(cb);
+}
+
+// fs_main_blinn_phong for one light and one fragment (render_mesh.wgsl:134-181, :256-281)
+__device__ __forceinline__ void add_light(const GpuLight& L, PixelInputs& p) {
+    float dx, dy, dz, intensity;
+    if (L.kind == RND_LIGHT_DIRECTIONAL) {
+        dx = L.dir[0]; dy = L.dir[1]; dz = L.dir[2];
+        float occlusion = 0.0f;
+        intensity = L.color[3] * (1.0f - occlusion);
+    } else {
+        float ox = p.fx - L.pos[0], oy = p.fy - L.pos[1], oz = p.fz - L.pos[2];
+        float d2 = dot3(ox, oy, oz, ox, oy, oz);
+#if RND_FAST_SHADE
+        float inv_d = rsqrt_f(d2);
+        float dist = d2 * inv_d;
+        if (!(dist <= L.radius)) return;
+        float lin = fminf(fmaxf((L.radius - dist) * L.inv_radius, 0.0f), 1.0f);
+#else
+        float dist = sqrtf(d2);
+        if (dist > L.radius) return;
+        float inv_d = 1.0f / dist;
+        float lin = fminf(fmaxf((L.radius - dist) / L.radius, 0.0f), 1.0f);
+#endif
+        dx = ox * inv_d; dy = oy * inv_d; dz = oz * inv_d;
+        float att = (lin * lin) * (3.0f - 2.0f * lin);
+        intensity = L.color[3] * att;
+    }
+    float tx = -dx, ty = -dy, tz = -dz;
+    float diff = fmaxf(dot3(p.Nx, p.Ny, p.Nz, tx, ty, tz), 0.0f);
+    float lr = L.color[0] * intensity, lg = L.color[1] * intensity, lb = L.color[2] * intensity;
+    float hx = tx + p.Vx, hy = ty + p.Vy, hz = tz + p.Vz;
+    float inv_h = rsqrt_f(dot3(hx, hy, hz, hx, hy, hz));
+    hx *= inv_h; hy *= inv_h; hz *= inv_h;
+    float sp = fmaxf(dot3(p.Nx, p.Ny, p.Nz, hx, hy, hz), 0.0f);
+    float s2 = sp * sp, s4 = s2 * s2, s8 = s4 * s4;
+    p.cr = p.cr + p.br * (lr * diff + lr * s8);
+    p.cg = p.cg + p.bg * (lg * diff + lg * s8);
+    p.cb = p.cb + p.bb * (lb * diff + lb * s8);
 }
 
 __global__ __launch_bounds__(256) void k_shade(FrameBuffers fb, FrameConst fc) {
     __shared__ GpuLight s_lights[kMaxLights];
-    const uint32_t tid = threadIdx.x;
+    __shared__ uint16_t s_list[kMaxLights];
+    __shared__ float s_box[4][6];
+    __shared__ uint32_t s_cnt[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     {
         const uint32_t n_words = fc.n_lights * (uint32_t)(sizeof(GpuLight) / 4);
         const uint32_t* src = reinterpret_cast<const uint32_t*>(fb.lights);
         uint32_t* dst = reinterpret_cast<uint32_t*>(s_lights);
         for (uint32_t k = tid; k < n_words; k += 256u) dst[k] = src[k];
     }
-    __syncthreads();
     const TileRef ref = fb.launch_order[blockIdx.x];
     const uint32_t tile_x0 = (ref.tile % fc.tiles_x) * kTile, tile_y0 = (ref.tile / fc.tiles_x) * kTile;
     const unsigned long long* vis = reinterpret_cast<const unsigned long long*>(fb.vis) + (size_t)ref.tile * kTilePixels;
+
+    // phase A: fragment inputs of this lane's four pixels
+    PixelInputs px[4];
+    unsigned long long key[4];
+    bool covered[4];
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        uint32_t local = k * 256u + tid;
+        uint32_t i = tile_x0 + (local & (kTile - 1)), j = tile_y0 + (local / kTile);
+        key[k] = vis[local];
+        uint32_t id = (uint32_t)(key[k] & 0xFFFFFFFFull);
+        covered[k] = i < fc.width && j < fc.height && id != RND_NONE;
+        px[k].lit = false;
+        px[k].cr = fc.clear_hdr[0]; px[k].cg = fc.clear_hdr[1]; px[k].cb = fc.clear_hdr[2];
+        if (covered[k]) {
+            prepare_pixel(fb, fc, id, i, j, px[k]);
+            if (px[k].lit) {
+                lo[0] = fminf(lo[0], px[k].fx); lo[1] = fminf(lo[1], px[k].fy); lo[2] = fminf(lo[2], px[k].fz);
+                hi[0] = fmaxf(hi[0], px[k].fx); hi[1] = fmaxf(hi[1], px[k].fy); hi[2] = fmaxf(hi[2], px[k].fz);
+            }
+        }
+    }
+    // phase B: lights that can reach the tile.  A point light whose sphere misses the bounding box
+    // of the tile's fragments adds exactly zero to every one of them (distance > radius discards),
+    // so dropping it changes nothing; the list keeps the lights in their original order.
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[c] = fminf(lo[c], __shfl_xor(lo[c], o));
+            hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], o));
+        }
+    if (lane == 0) {
+        s_box[wave][0] = lo[0]; s_box[wave][1] = lo[1]; s_box[wave][2] = lo[2];
+        s_box[wave][3] = hi[0]; s_box[wave][4] = hi[1]; s_box[wave][5] = hi[2];
+    }
+    __syncthreads();
+    bool keep = false;
+    if (tid < fc.n_lights) {
+        float blo[3], bhi[3];
+        for (int c = 0; c < 3; ++c) {
+            blo[c] = fminf(fminf(s_box[0][c], s_box[1][c]), fminf(s_box[2][c], s_box[3][c]));
+            bhi[c] = fmaxf(fmaxf(s_box[0][c + 3], s_box[1][c + 3]), fmaxf(s_box[2][c + 3], s_box[3][c + 3]));
+        }
+        const GpuLight& L = s_lights[tid];
+        if (blo[0] <= bhi[0]) {
+            if (L.kind == RND_LIGHT_DIRECTIONAL) keep = true;
+            else {
+                float dd = 0.0f;
+                for (int c = 0; c < 3; ++c) {
+                    float e = fmaxf(fmaxf(blo[c] - L.pos[c], L.pos[c] - bhi[c]), 0.0f);
+                    dd += e * e;
+                }
+                float rr = L.radius * 1.001f + 1.0e-6f;      // conservative: never drop a light that could pass
+                keep = dd <= rr * rr;
+            }
+        }
+    }
+    unsigned long long km = __ballot(keep);
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(km);
+    __syncthreads();
+    uint32_t base = 0, n_list = 0;
+    for (uint32_t w = 0; w < 4; ++w) {
+        if (w < wave) base += s_cnt[w];
+        n_list += s_cnt[w];
+    }
+    if (keep) s_list[base + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = (uint16_t)tid;
+    __syncthreads();
+    // phase C: light loop
+    for (uint32_t li = 0; li < n_list; ++li) {
+        const GpuLight& L = s_lights[s_list[li]];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k)
+            if (px[k].lit) add_light(L, px[k]);
+    }
+    // phase D: f16 target, tone map, sRGB (show_texture.wgsl + the sRGB surface)
+#pragma unroll
     for (uint32_t k = 0; k < 4; ++k) {
         uint32_t local = k * 256u + tid;
         uint32_t i = tile_x0 + (local & (kTile - 1)), j = tile_y0 + (local / kTile);
         bool inside = i < fc.width && j < fc.height;
-        unsigned long long key = vis[local];
-        uint32_t id = (uint32_t)(key & 0xFFFFFFFFull);
-        float hdr[3] = {fc.clear_hdr[0], fc.clear_hdr[1], fc.clear_hdr[2]};
-        if (inside && id != RND_NONE) shade_pixel(fb, fc, s_lights, id, i, j, hdr);
-        // show_texture.wgsl: Reinhard on luminance, then the sRGB surface
-        float r = hdr[0], g = hdr[1], b = hdr[2];
+        float hr = round_f16(px[k].cr), hg = round_f16(px[k].cg), hb = round_f16(px[k].cb);
+        float r = hr, g = hg, b = hb;
         if (fc.tone == RND_TONE_MAPPING_REINHARD) {
             float lum = (0.2126f * r + 0.7152f * g) + 0.0722f * b;
-            float dd = lum + 1.0f;
+            float inv = rcp_f(lum + 1.0f);
+#if RND_FAST_SHADE
+            r = r * inv; g = g * inv; b = b * inv;
+#else
+            float dd = lum + 1.0f; (void)inv;
             r = r / dd; g = g / dd; b = b / dd;
+#endif
         }
-        uint32_t rgba = srgb8(r) | (srgb8(g) << 8) | (srgb8(b) << 16) | 0xFF000000u;
+        uint32_t rgba = srgb8_f(r) | (srgb8_f(g) << 8) | (srgb8_f(b) << 16) | 0xFF000000u;
         if (fb.tiles_rgba8) reinterpret_cast<uint32_t*>(fb.tiles_rgba8)[(size_t)ref.compact * kTilePixels + local] = inside ? rgba : 0u;
         if (inside) {
             size_t p = (size_t)j * fc.width + i;
             if (fb.frame_rgba8) reinterpret_cast<uint32_t*>(fb.frame_rgba8)[p] = rgba;
-            if (fb.packed) reinterpret_cast<unsigned long long*>(fb.packed)[p] = (key & 0xFFFFFFFF00000000ull) | rgba;
-            if (fb.hdr) { fb.hdr[p * 3] = hdr[0]; fb.hdr[p * 3 + 1] = hdr[1]; fb.hdr[p * 3 + 2] = hdr[2]; }
+            if (fb.packed) reinterpret_cast<unsigned long long*>(fb.packed)[p] = (key[k] & 0xFFFFFFFF00000000ull) | rgba;
+            if (fb.hdr) { fb.hdr[p * 3] = hr; fb.hdr[p * 3 + 1] = hg; fb.hdr[p * 3 + 2] = hb; }
         }
     }
 }
@@ -704,7 +850,7 @@ void launch_transform(const FrameBuffers& fb, const FrameConst& fc, hipStream_t 
 }
 void launch_setup(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {
     if (!fc.n_tris) return;
-    hipLaunchKernelGGL(k_setup, dim3(div_up(fc.n_tris, 256)), dim3(256), 0, stream, fb, fc, cap);
+    hipLaunchKernelGGL(k_setup, dim3(div_up(fc.n_tris, kSetupChunk)), dim3(256), 0, stream, fb, fc, cap);
 }
 void launch_clip(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {
     if (!fc.n_tris) return;

@@ -308,6 +308,7 @@ void VisualServer::build_frame(std::vector<DrawItem>& items, std::vector<uint32_
         g.radius = l.light.radius; g.kind = l.light.kind;
         std::memcpy(g.color, l.light.color, 16);
         g.shadow_index = -1;
+        g.inv_radius = l.light.radius > 0.0f ? 1.0f / l.light.radius : 0.0f;
         lights.push_back(g);
     }
     FrameConst& fc = fc_;
@@ -335,7 +336,9 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     const size_t n_tiles = (size_t)tiles_x_ * tiles_y_;
 
     // capacities
-    if (cap_.records < (uint64_t)fc.n_tris + fc.n_tris / 8 + 4096) cap_.records = fc.n_tris + fc.n_tris / 8 + 4096;
+    cap_.setup_slots = setup_slots_for(fc.n_tris);
+    clip_records_ = std::max<uint32_t>(clip_records_, fc.n_tris / 8 + 4096);
+    cap_.records = (uint32_t)std::min<uint64_t>((uint64_t)cap_.setup_slots + clip_records_, 0xFFFFFFF0ull);
     if (cap_.clip_queue < std::max<uint32_t>(fc.n_tris / 8, 65536)) cap_.clip_queue = std::max<uint32_t>(fc.n_tris / 8, 65536);
     const uint64_t want_entries = std::max<uint64_t>(4ull * cap_.records + 16ull * n_tiles, 1u << 20);
     if (cap_.entries < want_entries) cap_.entries = (uint32_t)std::min<uint64_t>(want_entries, 0xFFFFFFF0ull);
@@ -432,7 +435,7 @@ void VisualServer::finish() {
         const FrameCounters c = *h_counters_;
         if (!c.overflow) break;
         // an internal stream was too small: grow it to what the frame asked for and run it again
-        if (c.overflow & 1u) cap_.records = (uint32_t)std::min<uint64_t>((uint64_t)c.n_records + c.n_records / 4 + 4096, 0xFFFFFFF0ull);
+        if (c.overflow & 1u) clip_records_ = (uint32_t)std::min<uint64_t>((uint64_t)c.n_records + c.n_records / 4 + 4096, 0x7FFFFFF0ull);
         if (c.overflow & 2u) cap_.clip_queue = (uint32_t)std::min<uint64_t>((uint64_t)c.n_clip + c.n_clip / 4 + 4096, 0xFFFFFFF0ull);
         if (c.overflow & 4u) cap_.entries = (uint32_t)std::min<uint64_t>((uint64_t)c.n_entries + c.n_entries / 4 + 4096, 0xFFFFFFF0ull);
         grew = 1;
@@ -440,7 +443,7 @@ void VisualServer::finish() {
         enqueue_frame(false);
     }
     const FrameCounters c = *h_counters_;
-    stats_.n_setup = c.n_records; stats_.n_bin_entries = c.n_entries; stats_.overflow = grew;
+    stats_.n_setup = c.n_valid; stats_.n_bin_entries = c.n_entries; stats_.overflow = grew;
     // pixels this context rasterizes: owned tiles clipped to the frame
     uint64_t px = 0;
     for (uint32_t t : owned_tiles(rank_, world_)) {
