@@ -126,31 +126,23 @@ def main():
     vs = VisualServer(scene.width, scene.height, device=local_rank)
     stream = torch.cuda.Stream(device=local_rank)
     vs.set_stream(stream.cuda_stream)
-    gather_list, tiles = None, None
+    gather = None
     if world > 1:
+        from renderer_amd.sort_first import TileGather
         vs.set_tile_partition(rank, world)
         info = vs.tile_info()
-        counts = [0] * world
-        t = torch.tensor([info["n_owned"]], device="cuda")
-        allc = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(allc, t)
-        counts = [int(c.item()) for c in allc]
-        tile_bytes = info["tile_px"] * info["tile_px"] * 4
-        # equal-sized gather buffers: pad every rank to the largest tile count
-        tiles = torch.zeros(max(counts) * tile_bytes, dtype=torch.uint8, device="cuda")
-        vs.set_tiles_output(tiles.data_ptr(), tiles.numel())
-        if rank == 0:
-            gather_list = [torch.empty_like(tiles) for _ in range(world)]
+        gather = TileGather(rank, world, info["n_owned"], info["tile_px"], "cuda")
+        vs.set_tiles_output(gather.tiles.data_ptr(), gather.tiles.numel())
     driver = FrameDriver(vs, scene)
 
     def step():
         with torch.cuda.stream(stream):
             driver.frame()
             if world > 1:
-                dist.gather(tiles, gather_list, dst=0)
+                gathered = gather.gather()
                 if rank == 0:
                     for r in range(world):
-                        vs.api.detile(vs._ctx, r, world, C.c_void_p(gather_list[r].data_ptr()))
+                        vs.api.detile(vs._ctx, r, world, C.c_void_p(gathered[r].data_ptr()))
 
     def fence():
         vs.finish()

@@ -285,8 +285,8 @@ static constexpr uint32_t QUAD_MESH_ID = 0xFFFFFFFEu;
 
 static bool owns_tile(const Ctx& c, uint32_t tx, uint32_t ty) {
     if (c.world <= 1) return true;
-    uint32_t gx = tx / GROUP, gy = ty / GROUP;
-    return ((gx + gy * 3u) % c.world) == c.rank;
+    (void)tx;
+    return ((ty / GROUP) % c.world) == c.rank;   // full-width stripes of GROUP tile rows
 }
 static bool owns_pixel(const Ctx& c, uint32_t i, uint32_t j) { return owns_tile(c, i / TILE, j / TILE); }
 

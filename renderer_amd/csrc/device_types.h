@@ -8,7 +8,7 @@ namespace rnd {
 
 constexpr uint32_t kTile = 32;                 // square screen tile edge in pixels
 constexpr uint32_t kTilePixels = kTile * kTile;
-constexpr uint32_t kOwnerGroup = 4;            // sort-first ownership granularity, in tiles
+constexpr uint32_t kOwnerGroup = 4;            // sort-first ownership: full-width stripes of this many tile rows, dealt round-robin
 constexpr int kSubpixelBits = 8;
 constexpr int kSub = 1 << kSubpixelBits;       // 256 sub-pixel steps per pixel
 constexpr float kGuardBand = 16.0f;            // guard band half-extent in NDC units

@@ -38,7 +38,8 @@ __device__ __forceinline__ uint32_t find_item(const uint32_t* __restrict__ bases
 
 __device__ __forceinline__ bool owns_tile(uint32_t tx, uint32_t ty, uint32_t rank, uint32_t world) {
     if (world <= 1) return true;
-    return (((tx / kOwnerGroup) + (ty / kOwnerGroup) * 3u) % world) == rank;
+    (void)tx;
+    return ((ty / kOwnerGroup) % world) == rank;   // full-width stripes of kOwnerGroup tile rows
 }
 
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
@@ -137,10 +138,9 @@ __device__ __forceinline__ uint32_t pack_tileword(const TileRect& t) {
 __device__ __forceinline__ bool any_owned(const TileRect& t, const FrameConst& fc) {
     if (fc.world <= 1) return true;
     // rects spanning a whole ownership period in x or y always contain an owned tile
-    if (t.tx1 - t.tx0 >= kOwnerGroup * fc.world || t.ty1 - t.ty0 >= kOwnerGroup * fc.world) return true;
+    if (t.ty1 - t.ty0 >= kOwnerGroup * fc.world) return true;
     for (uint32_t ty = t.ty0; ty <= t.ty1; ++ty)
-        for (uint32_t tx = t.tx0; tx <= t.tx1; ++tx)
-            if (owns_tile(tx, ty, fc.rank, fc.world)) return true;
+        if (owns_tile(t.tx0, ty, fc.rank, fc.world)) return true;
     return false;
 }
 

@@ -4,6 +4,7 @@
 // Operation order is fixed (see DESIGN.md "Host math"); build with -ffp-contract=off.
 #pragma once
 #include <cmath>
+#include <cstdint>
 #include <cstring>
 
 namespace rnd {
@@ -146,7 +147,31 @@ inline Mat4 inverse(const Mat4& mm) {
 
 // IEEE binary16 round-to-nearest-even, widened back to f32 (the Rgba16Float clear colour)
 inline float round_to_f16(float f) {
-    return (float)(_Float16)f;
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    const uint32_t sign = u & 0x80000000u;
+    uint32_t mag = u & 0x7FFFFFFFu;
+    if (mag >= 0x7F800000u) return f;                      // inf, nan
+    const int exp = (int)(mag >> 23) - 127;
+    if (exp > 15 || (exp == 15 && (mag & 0x007FFFFFu) >= 0x007FF000u)) mag = 0x7F800000u;   // >= 65520 -> inf
+    else {
+        // number of low mantissa bits a binary16 cannot hold: 13 for normals, more below 2^-14
+        const int drop = exp >= -14 ? 13 : (exp >= -25 ? 13 + (-14 - exp) : 25);
+        if (drop >= 25) mag = 0;                           // below half the smallest subnormal
+        else {
+            const uint32_t full = (mag & 0x007FFFFFu) | 0x00800000u;   // explicit leading one
+            const uint32_t unit = 1u << drop, rem = full & (unit - 1u), half = unit >> 1;
+            uint32_t kept = full >> drop;
+            if (rem > half || (rem == half && (kept & 1u))) kept += 1;
+            // rebuild: value = kept * 2^(exp - 23 + drop)
+            float v = std::ldexp((float)kept, exp - 23 + drop);
+            std::memcpy(&mag, &v, 4);
+        }
+    }
+    const uint32_t out = sign | mag;
+    float r;
+    std::memcpy(&r, &out, 4);
+    return r;
 }
 
 }  // namespace rnd

@@ -115,7 +115,7 @@ std::vector<uint32_t> VisualServer::owned_tiles(uint32_t rank, uint32_t world) c
     std::vector<uint32_t> out;
     for (uint32_t ty = 0; ty < tiles_y_; ++ty)
         for (uint32_t tx = 0; tx < tiles_x_; ++tx)
-            if (world <= 1 || (((tx / kOwnerGroup) + (ty / kOwnerGroup) * 3u) % world) == rank) out.push_back(ty * tiles_x_ + tx);
+            if (world <= 1 || ((ty / kOwnerGroup) % world) == rank) out.push_back(ty * tiles_x_ + tx);
     return out;
 }
 

@@ -1,0 +1,73 @@
+"""Multi-GPU frame assembly: one process per GPU, torch.distributed (RCCL on GPUs, gloo in CPU tests).
+
+sort-first  every rank rasterizes/shades the screen tiles it owns (full-width stripes of 4 tile rows
+            dealt round-robin, rnd_set_tile_partition); the finished tile-major RGBA8 buffers are
+            gathered to rank 0 (each peer sends its own buffer straight to rank 0: over xGMI that is
+            one link per peer, no ring) and scattered into the row-major frame there.
+sort-last   every rank renders its own mesh shard at full resolution into a packed
+            (depth bits << 32 | rgba8) frame; a MIN reduction to rank 0 is the depth composite
+            (depth in [0,1] makes the IEEE bits order-preserving; the packed value is < 2^62, so the
+            signed int64 view orders the same way).
+
+The reference is single-device; this module has no counterpart there.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+OWNER_GROUP = 4     # tile rows per ownership stripe (csrc/device_types.h kOwnerGroup)
+
+
+def owned_tiles(rank, world, tiles_x, tiles_y):
+    """Ascending tile indices owned by `rank` (must match rnd::VisualServer::owned_tiles)."""
+    return [ty * tiles_x + tx for ty in range(tiles_y) if world <= 1 or (ty // OWNER_GROUP) % world == rank
+            for tx in range(tiles_x)]
+
+
+def detile_numpy(frame, tiles_rgba8, tile_list, tile_px, tiles_x):
+    """Host version of rnd_detile: scatter tile-major RGBA8 tiles into a row-major (H, W, 4) frame."""
+    h, w = frame.shape[:2]
+    t = np.asarray(tiles_rgba8, dtype=np.uint8).reshape(-1, tile_px, tile_px, 4)
+    for k, tile in enumerate(tile_list):
+        x0, y0 = (tile % tiles_x) * tile_px, (tile // tiles_x) * tile_px
+        x1, y1 = min(x0 + tile_px, w), min(y0 + tile_px, h)
+        frame[y0:y1, x0:x1] = t[k, :y1 - y0, :x1 - x0]
+    return frame
+
+
+class TileGather:
+    """Equal-sized gather buffers for the tile-major outputs of all ranks (padded to the largest)."""
+
+    def __init__(self, rank, world, n_owned, tile_px, device):
+        self.rank, self.world, self.tile_bytes = rank, world, tile_px * tile_px * 4
+        t = torch.tensor([n_owned], dtype=torch.int64, device=device)
+        counts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(counts, t)
+        self.counts = [int(c.item()) for c in counts]
+        self.tiles = torch.zeros(max(max(self.counts), 1) * self.tile_bytes, dtype=torch.uint8, device=device)
+        self.gathered = [torch.empty_like(self.tiles) for _ in range(world)] if rank == 0 else None
+
+    def gather(self):
+        """Collect every rank's `tiles` buffer on rank 0 (a send/recv group, no ring)."""
+        dist.gather(self.tiles, self.gathered, dst=0)
+        return self.gathered
+
+
+def depth_composite(packed):
+    """Sort-last composite: element-wise MIN of the packed int64 frames onto rank 0 (in place)."""
+    dist.reduce(packed, dst=0, op=dist.ReduceOp.MIN)
+    return packed
+
+
+def pack_numpy(depth, rgba8):
+    """Host version of the packed frame: (f32 depth bits << 32) | rgba8 little-endian word."""
+    d = np.ascontiguousarray(depth, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    c = np.ascontiguousarray(rgba8, dtype=np.uint8).view(np.uint32).reshape(d.shape).astype(np.uint64)
+    return ((d << np.uint64(32)) | c).view(np.int64)
+
+
+def unpack_numpy(packed):
+    p = np.asarray(packed).view(np.uint64)
+    depth = (p >> np.uint64(32)).astype(np.uint32).view(np.float32)
+    rgba = (p & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.uint8).reshape(p.shape + (4,))
+    return depth, rgba
