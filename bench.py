@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--scale", type=float, default=1.0, help="linear mesh-density scale (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--lights", type=int, default=-1, help="keep only the first N lights (debug only)")
     return ap.parse_args()
 
 
@@ -122,6 +123,9 @@ def main():
     builder, desc = WORKLOADS[args.workload]
     kwargs = {"scale": args.scale} if args.workload in ("c2", "c3", "c4") and args.scale != 1.0 else {}
     scene = getattr(scenes, builder)(**kwargs)
+    if args.lights >= 0:
+        scene.lights = scene.lights[:args.lights]
+        desc += f" (first {args.lights} lights only)"
 
     vs = VisualServer(scene.width, scene.height, device=local_rank)
     stream = torch.cuda.Stream(device=local_rank)

@@ -223,8 +223,8 @@ static inline void barycentrics(const V4& c0, const V4& c1, const V4& c2, uint32
                                 uint32_t W, uint32_t H, float b[3]) {
     double x0 = c0.x, y0 = c0.y, w0 = c0.w, x1 = c1.x, y1 = c1.y, w1 = c1.w, x2 = c2.x, y2 = c2.y,
            w2 = c2.w;
-    double xn = (2.0 * ((double)i + 0.5)) / (double)W - 1.0;
-    double yn = 1.0 - (2.0 * ((double)j + 0.5)) / (double)H;
+    double xn = ((double)i + 0.5) * (2.0 / (double)W) - 1.0;
+    double yn = 1.0 - ((double)j + 0.5) * (2.0 / (double)H);
     // n0 = P1 x P2, n1 = P2 x P0, n2 = P0 x P1 with P = (x, y, w)
     double e0 = ((y1 * w2 - w1 * y2) * xn + (w1 * x2 - x1 * w2) * yn) + (x1 * y2 - y1 * x2);
     double e1 = ((y2 * w0 - w2 * y0) * xn + (w2 * x0 - x2 * w0) * yn) + (x2 * y0 - y2 * x0);

@@ -25,7 +25,7 @@ enum : uint32_t {
 };
 
 // One (instance, submesh) pair of VisualServer::render's draw list (visual_server.rs:225-245).
-struct DrawItem {
+struct alignas(16) DrawItem {
     const float* px;            // SoA object-space positions, read by the vertex-transform kernel
     const float* py;
     const float* pz;
@@ -41,8 +41,9 @@ struct DrawItem {
     float base_color[4];        // MaterialUniform.base_color
     uint32_t flags;
     uint32_t texture;           // index into the texture table, RND_NONE = white
-    uint32_t pad[2];
+    uint32_t pad[4];
 };
+static_assert(sizeof(DrawItem) == 240, "DrawItem is copied in 16-byte pieces");
 
 // LightUniform (visual_server.rs:987-996) reduced to what fs_main_blinn_phong reads.
 struct GpuLight {
@@ -69,6 +70,7 @@ struct FrameConst {
     uint32_t n_items, n_lights;
     uint32_t n_tris, n_verts;
     uint32_t rank, world;
+    double ndc_step_x, ndc_step_y;   // 2/width, 2/height in f64 (pixel centre -> NDC at shade time)
 };
 
 // Setup record of one (sub-)triangle after cull / clip / snap: 48 bytes.

@@ -20,11 +20,11 @@ struct FrameBuffers {
     // geometry stage
     float4* clip;                   // n_verts clip positions
     SetupRecord* records;
-    uint32_t* tilewords;            // per record: tx0 | ty0<<8 | (w-1)<<16 | (h-1)<<24
+    uint2* tilewords;               // per record: .x = tx0 | ty0<<8 | (w-1)<<16 | (h-1)<<24, .y = position in its bin (single-tile records)
     uint32_t* clip_queue;           // triangle ids that need the clipper
-    uint32_t* tile_count;           // per tile
+    uint32_t* tile_count;           // [0,T): single-tile records per tile; [T,2T): multi-tile records per tile
     uint32_t* tile_offset;          // per tile, exclusive scan of tile_count
-    uint32_t* tile_cursor;          // per tile, fill cursor
+    uint32_t* tile_cursor;          // per tile, fill cursor of the multi-tile records
     uint32_t* entries;              // bin entries: record slots, grouped by tile
     FrameCounters* counters;
     // pixel stage

@@ -24,6 +24,17 @@ uint32_t setup_slots_for(uint32_t n_tris) { return (uint32_t)(((uint64_t)n_tris 
 // ------------------------------------------------------------------------------------------
 // helpers
 // ------------------------------------------------------------------------------------------
+constexpr uint32_t kLdsItems = 1023;       // draw-item tables up to this size are searched in LDS
+
+// Internal consistency checks: an index that would leave its buffer sets a bit of
+// FrameCounters::overflow (reported by rnd_finish as RND_ERR_DEVICE) and the access is skipped,
+// instead of faulting the GPU.
+enum : uint32_t { kGuardSetup = 0x100u, kGuardCount = 0x200u, kGuardBin = 0x400u, kGuardRaster = 0x800u, kGuardShade = 0x1000u };
+__device__ __forceinline__ bool guard(bool ok, FrameCounters* counters, uint32_t bit) {
+    if (!ok) atomicOr(&counters->overflow, bit);
+    return ok;
+}
+
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
 // largest k in [0, n) with bases[k] <= id (bases[0] == 0, ascending)
@@ -46,6 +57,66 @@ __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, fl
     return (ax * bx + ay * by) + az * bz;
 }
 
+// Pointers read out of a DrawItem are generic to the compiler (flat_load, which also ties up the
+// LDS counter); these casts make the loads through them plain global loads.
+typedef const __attribute__((address_space(1))) uint32_t* gptr_u32;
+typedef const __attribute__((address_space(1))) float* gptr_f32;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) f32x4* gptr_f32x4;
+
+// Waterfall helper: picks the value of `v` held by the first lane of `pending` as a scalar.
+// Two things make the obvious `cur = readfirstlane(v); if (cur == v) {...}` loop unsafe: the
+// optimizer may hoist the (loop-invariant) readfirstlane out of the loop, and inside the
+// `cur == v` branch it may substitute the per-lane `v` for `cur`, turning scalar loads into
+// per-lane ones.  Here the lane is chosen from the loop-variant `pending` mask, and the value
+// used for addressing passes through an empty asm, so no equality with `v` is known for it.
+__device__ __forceinline__ uint32_t uniform_pick(uint32_t v, unsigned long long pending, uint32_t& opaque) {
+    uint32_t cur = __builtin_amdgcn_readlane(v, __ffsll((long long)pending) - 1);
+    opaque = cur;
+    asm volatile("" : "+s"(opaque));
+    return cur;
+}
+
+// Copies one wave-uniform draw item into registers through the constant address space, which the
+// compiler always serves with scalar loads (the table is never written while a kernel reads it).
+__device__ __forceinline__ DrawItem load_item_uniform(const DrawItem* items, uint32_t index) {
+    // `index` must be wave-uniform (see uniform_pick).
+    // member-wise, typed copies: punning the struct through integer vectors would let type-based
+    // alias analysis treat the float and pointer fields as never written
+    typedef const __attribute__((address_space(4))) DrawItem* cptr_item;
+    cptr_item p = (cptr_item)items + index;
+    DrawItem d;
+    d.px = p->px; d.py = p->py; d.pz = p->pz; d.verts = p->verts; d.indices = p->indices;
+    d.n_verts = p->n_verts; d.n_tris = p->n_tris; d.vert_base = p->vert_base; d.tri_base = p->tri_base;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { d.world[k] = p->world[k]; d.nrm[k] = p->nrm[k]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { d.fixed_clip[k] = p->fixed_clip[k]; d.base_color[k] = p->base_color[k]; }
+    d.flags = p->flags; d.texture = p->texture;
+    return d;
+}
+
+// vs_main's clip position (render_mesh.wgsl:42-82).  K1 stores it; the shading kernel re-derives
+// it from the object-space position it gathers anyway: same inputs, same operations, same bits.
+__device__ __forceinline__ float4 clip_position(const DrawItem& d, const FrameConst& fc, float x, float y, float z) {
+    float4 c;
+    if ((d.flags & kItemBillboardMask) == RND_BILLBOARD_FIXED_SIZE) {
+        c = make_float4(d.fixed_clip[0] + x * 0.4f, d.fixed_clip[1] + y * 0.4f, d.fixed_clip[2], d.fixed_clip[3]);
+    } else {
+        const float* m = d.world;
+        float wx = ((m[0] * x + m[4] * y) + m[8] * z) + m[12];
+        float wy = ((m[1] * x + m[5] * y) + m[9] * z) + m[13];
+        float wz = ((m[2] * x + m[6] * y) + m[10] * z) + m[14];
+        float ww = ((m[3] * x + m[7] * y) + m[11] * z) + m[15];
+        const float* p = fc.pv;
+        c.x = ((p[0] * wx + p[4] * wy) + p[8] * wz) + p[12] * ww;
+        c.y = ((p[1] * wx + p[5] * wy) + p[9] * wz) + p[13] * ww;
+        c.z = ((p[2] * wx + p[6] * wy) + p[10] * wz) + p[14] * ww;
+        c.w = ((p[3] * wx + p[7] * wy) + p[11] * wz) + p[15] * ww;
+    }
+    return c;
+}
+
 // ------------------------------------------------------------------------------------------
 // K1: vertex transform.  One thread per (draw item, vertex); positions are read from three SoA
 // streams (4 B/lane, fully coalesced), the clip position is written as one 16-byte store per lane.
@@ -58,30 +129,16 @@ __global__ __launch_bounds__(256) void k_transform(const DrawItem* __restrict__ 
     uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     if (gid >= fc.n_verts) return;
     uint32_t it = find_item(vert_bases, fc.n_items, gid);
-    for (;;) {
-        uint32_t cur = __builtin_amdgcn_readfirstlane(it);
-        if (cur == it) {
-            const DrawItem& d = items[cur];
+    for (unsigned long long pending = __ballot(true); pending;) {
+        uint32_t cur_s, cur = uniform_pick(it, pending, cur_s);
+        const bool mine = it == cur;
+        pending &= ~__ballot(mine);
+        if (mine) {
+            const DrawItem d = load_item_uniform(items, cur_s);
             uint32_t v = gid - d.vert_base;
-            float x = d.px[v], y = d.py[v], z = d.pz[v];
-            float4 c;
-            if ((d.flags & kItemBillboardMask) == RND_BILLBOARD_FIXED_SIZE) {
-                c = make_float4(d.fixed_clip[0] + x * 0.4f, d.fixed_clip[1] + y * 0.4f, d.fixed_clip[2],
-                                d.fixed_clip[3]);
-            } else {
-                const float* m = d.world;
-                float wx = ((m[0] * x + m[4] * y) + m[8] * z) + m[12];
-                float wy = ((m[1] * x + m[5] * y) + m[9] * z) + m[13];
-                float wz = ((m[2] * x + m[6] * y) + m[10] * z) + m[14];
-                float ww = ((m[3] * x + m[7] * y) + m[11] * z) + m[15];
-                const float* p = fc.pv;
-                c.x = ((p[0] * wx + p[4] * wy) + p[8] * wz) + p[12] * ww;
-                c.y = ((p[1] * wx + p[5] * wy) + p[9] * wz) + p[13] * ww;
-                c.z = ((p[2] * wx + p[6] * wy) + p[10] * wz) + p[14] * ww;
-                c.w = ((p[3] * wx + p[7] * wy) + p[11] * wz) + p[15] * ww;
-            }
+            float x = ((gptr_f32)d.px)[v], y = ((gptr_f32)d.py)[v], z = ((gptr_f32)d.pz)[v];
+            float4 c = clip_position(d, fc, x, y, z);
             clip[gid] = c;
-            break;
         }
     }
 }
@@ -144,47 +201,68 @@ __device__ __forceinline__ bool any_owned(const TileRect& t, const FrameConst& f
     return false;
 }
 
-// Adds this wave's records to the per-tile counts (mode 0) or scatters them into the bins
-// (mode 1).  Lanes whose record touches one tile are grouped by tile with ballots: one atomic per
-// (wave, tile), each lane taking base + its rank inside the group.  Must be called by all lanes
-// of the wave that are still active, with `emit` false on lanes that have nothing.
-template <int MODE>
-__device__ __forceinline__ void bin_wave(bool emit, const TileRect& t, uint32_t slot, const FrameConst& fc,
-                                         uint32_t* __restrict__ tile_counter,
-                                         const uint32_t* __restrict__ tile_offset,
-                                         uint32_t* __restrict__ entries, uint32_t cap_entries) {
+// Adds this wave's records to the per-tile counts.  Records that touch ONE tile (the bulk) are
+// grouped by tile with ballots: one returning atomic per (wave, tile) group on the "single" count,
+// and each lane's position inside the tile's bin is base + its rank in the group, so the later
+// bin fill needs no atomics for them.  The atomics' results are only consumed after the grouping
+// loop (one wait for all of them).  Records that touch several tiles are counted per tile in the
+// "multi" counts and get their bin positions from a cursor in k_bin_fill.
+// Must be called by all lanes of the wave that are still active (emit false = nothing to add).
+// Returns the in-bin position for single-tile records, kNoBinPos otherwise.
+constexpr uint32_t kNoBinPos = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint32_t count_wave(bool emit, const TileRect& t, const FrameConst& fc,
+                                               uint32_t* __restrict__ count_single,
+                                               uint32_t* __restrict__ count_multi, FrameCounters* counters) {
     const uint32_t lane = lane_id();
+    if (emit && !guard(t.tx1 < fc.tiles_x && t.ty1 < fc.tiles_y && t.tx0 <= t.tx1 && t.ty0 <= t.ty1, counters, kGuardCount)) emit = false;
     bool single = emit && t.tx0 == t.tx1 && t.ty0 == t.ty1;
-    uint32_t tile = t.ty0 * fc.tiles_x + t.tx0;
+    const uint32_t tile = t.ty0 * fc.tiles_x + t.tx0;
     if (single && !owns_tile(t.tx0, t.ty0, fc.rank, fc.world)) single = false, emit = false;
+    uint32_t my_base = 0, my_leader = lane, my_rank = 0;
     unsigned long long pending = __ballot(single);
     while (pending) {
         int leader = __ffsll((long long)pending) - 1;
         uint32_t lt = __shfl(tile, leader);
-        unsigned long long same = __ballot(single && tile == lt);
-        uint32_t base = 0;
-        if (lane == (uint32_t)leader) base = atomicAdd(&tile_counter[lt], (uint32_t)__popcll(same));
-        if (MODE == 1) {
-            base = __shfl(base, leader);
-            if (single && tile == lt) {
-                uint32_t idx = tile_offset[lt] + base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-                if (idx < cap_entries) entries[idx] = slot;
-            }
-        }
+        bool mine = single && tile == lt;
+        unsigned long long same = __ballot(mine);
+        if (lane == (uint32_t)leader) my_base = atomicAdd(&count_single[lt], (uint32_t)__popcll(same));
+        if (mine) { my_leader = (uint32_t)leader; my_rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull)); }
         pending &= ~same;
     }
+    uint32_t base = __shfl(my_base, my_leader);
     if (emit && !single) {
-        for (uint32_t ty = t.ty0; ty <= t.ty1; ++ty)
-            for (uint32_t tx = t.tx0; tx <= t.tx1; ++tx) {
-                if (!owns_tile(tx, ty, fc.rank, fc.world)) continue;
-                uint32_t tl = ty * fc.tiles_x + tx;
-                uint32_t pos = atomicAdd(&tile_counter[tl], 1u);
-                if (MODE == 1) {
-                    uint32_t idx = tile_offset[tl] + pos;
-                    if (idx < cap_entries) entries[idx] = slot;
-                }
-            }
+        for (uint32_t ty = t.ty0; ty <= t.ty1; ++ty) {
+            if (!owns_tile(t.tx0, ty, fc.rank, fc.world)) continue;
+            for (uint32_t tx = t.tx0; tx <= t.tx1; ++tx) atomicAdd(&count_multi[ty * fc.tiles_x + tx], 1u);
+        }
     }
+    return single ? base + my_rank : kNoBinPos;
+}
+
+// Reject / cull / snap / record of one triangle whose vertices need no clipping; sets need_clip
+// (and emits nothing) when it must go through the clipper.
+__device__ __forceinline__ void setup_triangle(const float4& c0, const float4& c1, const float4& c2, uint32_t gid,
+                                               const FrameConst& fc, float half_w, float half_h, SetupRecord& rec,
+                                               TileRect& tr, bool& emit, bool& need_clip) {
+    bool finite = isfinite(c0.x) && isfinite(c0.y) && isfinite(c0.z) && isfinite(c0.w) &&
+                  isfinite(c1.x) && isfinite(c1.y) && isfinite(c1.z) && isfinite(c1.w) &&
+                  isfinite(c2.x) && isfinite(c2.y) && isfinite(c2.z) && isfinite(c2.w);
+    // trivial reject against the view volume
+    bool out = (c0.x < -c0.w && c1.x < -c1.w && c2.x < -c2.w) || (c0.x > c0.w && c1.x > c1.w && c2.x > c2.w) ||
+               (c0.y < -c0.w && c1.y < -c1.w && c2.y < -c2.w) || (c0.y > c0.w && c1.y > c1.w && c2.y > c2.w) ||
+               (c0.z < 0.0f && c1.z < 0.0f && c2.z < 0.0f) || (c0.z > c0.w && c1.z > c1.w && c2.z > c2.w);
+    if (!finite || out) return;
+    float g0 = kGuardBand * c0.w, g1 = kGuardBand * c1.w, g2 = kGuardBand * c2.w;
+    need_clip = (c0.z < 0.0f) | (c0.z > c0.w) | (c0.x < -g0) | (c0.x > g0) | (c0.y < -g0) | (c0.y > g0) |
+                (c1.z < 0.0f) | (c1.z > c1.w) | (c1.x < -g1) | (c1.x > g1) | (c1.y < -g1) | (c1.y > g1) |
+                (c2.z < 0.0f) | (c2.z > c2.w) | (c2.x < -g2) | (c2.x > g2) | (c2.y < -g2) | (c2.y > g2);
+    if (need_clip) return;
+    Snapped s0, s1, s2;
+    bool ok0 = snap_vertex(c0.x, c0.y, c0.z, c0.w, half_w, half_h, s0);
+    bool ok1 = snap_vertex(c1.x, c1.y, c1.z, c1.w, half_w, half_h, s1);
+    bool ok2 = snap_vertex(c2.x, c2.y, c2.z, c2.w, half_w, half_h, s2);
+    if (ok0 && ok1 && ok2) emit = make_record(s0, s1, s2, gid, fc, rec, tr) && any_owned(tr, fc);
 }
 
 // Slots of the record stream are deterministic: workgroup b owns slots [b*kSetupChunk,
@@ -196,9 +274,16 @@ constexpr uint32_t kInvalidTileword = 0xFFFFFFFFu;
 
 __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, FrameConst fc, Capacities cap) {
     __shared__ uint32_t s_wave_cnt[2][4];
+    __shared__ uint32_t s_bases[kLdsItems + 1];
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const bool bases_in_lds = fc.n_items <= kLdsItems;
+    if (bases_in_lds) {
+        for (uint32_t k = threadIdx.x; k <= fc.n_items; k += 256u) s_bases[k] = fb.tri_bases[k];
+        __syncthreads();
+    }
     const uint32_t chunk_base = blockIdx.x * kSetupChunk;
     const float half_w = 0.5f * (float)fc.width, half_h = 0.5f * (float)fc.height;
+    const uint32_t n_tiles = fc.tiles_x * fc.tiles_y;
     uint32_t running = 0;
     for (uint32_t iter = 0; iter < kSetupChunk / 256u; ++iter) {
         const uint32_t gid = chunk_base + iter * 256u + threadIdx.x;
@@ -206,32 +291,28 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, FrameConst fc, C
         SetupRecord rec;
         TileRect tr{0, 0, 0, 0};
         if (gid < fc.n_tris) {
-            uint32_t it = find_item(fb.tri_bases, fc.n_items, gid);
-            const DrawItem& d = fb.items[it];
-            if (!(d.flags & kItemSkip)) {
-                uint32_t t = gid - d.tri_base;
-                const uint32_t* ix = d.indices + 3ull * t;
-                float4 c0 = fb.clip[d.vert_base + ix[0]];
-                float4 c1 = fb.clip[d.vert_base + ix[1]];
-                float4 c2 = fb.clip[d.vert_base + ix[2]];
-                bool finite = isfinite(c0.x) && isfinite(c0.y) && isfinite(c0.z) && isfinite(c0.w) &&
-                              isfinite(c1.x) && isfinite(c1.y) && isfinite(c1.z) && isfinite(c1.w) &&
-                              isfinite(c2.x) && isfinite(c2.y) && isfinite(c2.z) && isfinite(c2.w);
-                // trivial reject against the view volume
-                bool out = (c0.x < -c0.w && c1.x < -c1.w && c2.x < -c2.w) || (c0.x > c0.w && c1.x > c1.w && c2.x > c2.w) ||
-                           (c0.y < -c0.w && c1.y < -c1.w && c2.y < -c2.w) || (c0.y > c0.w && c1.y > c1.w && c2.y > c2.w) ||
-                           (c0.z < 0.0f && c1.z < 0.0f && c2.z < 0.0f) || (c0.z > c0.w && c1.z > c1.w && c2.z > c2.w);
-                if (finite && !out) {
-                    float g0 = kGuardBand * c0.w, g1 = kGuardBand * c1.w, g2 = kGuardBand * c2.w;
-                    need_clip = (c0.z < 0.0f) | (c0.z > c0.w) | (c0.x < -g0) | (c0.x > g0) | (c0.y < -g0) | (c0.y > g0) |
-                                (c1.z < 0.0f) | (c1.z > c1.w) | (c1.x < -g1) | (c1.x > g1) | (c1.y < -g1) | (c1.y > g1) |
-                                (c2.z < 0.0f) | (c2.z > c2.w) | (c2.x < -g2) | (c2.x > g2) | (c2.y < -g2) | (c2.y > g2);
-                    if (!need_clip) {
-                        Snapped s0, s1, s2;
-                        bool ok0 = snap_vertex(c0.x, c0.y, c0.z, c0.w, half_w, half_h, s0);
-                        bool ok1 = snap_vertex(c1.x, c1.y, c1.z, c1.w, half_w, half_h, s1);
-                        bool ok2 = snap_vertex(c2.x, c2.y, c2.z, c2.w, half_w, half_h, s2);
-                        if (ok0 && ok1 && ok2) emit = make_record(s0, s1, s2, gid, fc, rec, tr) && any_owned(tr, fc);
+            uint32_t it = bases_in_lds ? find_item(s_bases, fc.n_items, gid) : find_item(fb.tri_bases, fc.n_items, gid);
+            // waterfall over the (at most a few) draw items a wave's triangles belong to
+            for (unsigned long long pending = __ballot(true); pending;) {
+                uint32_t cur_s, cur = uniform_pick(it, pending, cur_s);
+                const bool mine = it == cur;
+                pending &= ~__ballot(mine);
+                if (mine) {
+                    typedef const __attribute__((address_space(4))) DrawItem* cptr_item;
+                    cptr_item d = (cptr_item)fb.items + cur_s;
+                    if (!(d->flags & kItemSkip)) {
+                        uint32_t t = gid - d->tri_base;
+                        gptr_u32 ix = (gptr_u32)d->indices + 3ull * t;
+                        const uint32_t vb = d->vert_base, nv = d->n_verts;
+                        if (guard(t < d->n_tris, fb.counters, kGuardSetup)) {
+                            const uint32_t i0 = ix[0], i1 = ix[1], i2 = ix[2];
+                            if (guard(i0 < nv && i1 < nv && i2 < nv && vb + nv <= fc.n_verts, fb.counters, kGuardSetup)) {
+                                float4 c0 = fb.clip[vb + i0];
+                                float4 c1 = fb.clip[vb + i1];
+                                float4 c2 = fb.clip[vb + i2];
+                                setup_triangle(c0, c1, c2, gid, fc, half_w, half_h, rec, tr, emit, need_clip);
+                            }
+                        }
                     }
                 }
             }
@@ -260,15 +341,15 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, FrameConst fc, C
         }
         const uint32_t slot = chunk_base + running + wave_base + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
         running += total;
-        if (emit) {
+        const uint32_t pos = count_wave(emit, tr, fc, fb.tile_count, fb.tile_count + n_tiles, fb.counters);
+        if (emit && guard(slot < cap.records, fb.counters, kGuardSetup)) {
             float4* dst = reinterpret_cast<float4*>(fb.records + slot);
             const float4* src = reinterpret_cast<const float4*>(&rec);
             dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
-            fb.tilewords[slot] = pack_tileword(tr);
+            fb.tilewords[slot] = make_uint2(pack_tileword(tr), pos);
         }
-        bin_wave<0>(emit, tr, slot, fc, fb.tile_count, nullptr, nullptr, 0);
     }
-    for (uint32_t k = running + threadIdx.x; k < kSetupChunk; k += 256u) fb.tilewords[chunk_base + k] = kInvalidTileword;
+    for (uint32_t k = running + threadIdx.x; k < kSetupChunk; k += 256u) fb.tilewords[chunk_base + k] = make_uint2(kInvalidTileword, kNoBinPos);
     if (threadIdx.x == 0 && running) atomicAdd(&fb.counters->n_valid, running);
 }
 
@@ -304,7 +385,7 @@ __global__ __launch_bounds__(256) void k_clip(FrameBuffers fb, FrameConst fc, Ca
         uint32_t it = find_item(fb.tri_bases, fc.n_items, gid);
         const DrawItem& d = fb.items[it];
         uint32_t t = gid - d.tri_base;
-        const uint32_t* ix = d.indices + 3ull * t;
+        gptr_u32 ix = (gptr_u32)d.indices + 3ull * t;
         ClipVert a[12], b[12];
         for (int k = 0; k < 3; ++k) {
             float4 c = fb.clip[d.vert_base + ix[k]];
@@ -338,10 +419,11 @@ __global__ __launch_bounds__(256) void k_clip(FrameBuffers fb, FrameConst fc, Ca
             if (slot >= cap.records) { atomicOr(&fb.counters->overflow, 1u); continue; }
             atomicAdd(&fb.counters->n_valid, 1u);
             fb.records[slot] = rec;
-            fb.tilewords[slot] = pack_tileword(tr);
+            fb.tilewords[slot] = make_uint2(pack_tileword(tr), kNoBinPos);
+            uint32_t* count_multi = fb.tile_count + fc.tiles_x * fc.tiles_y;
             for (uint32_t ty = tr.ty0; ty <= tr.ty1; ++ty)
                 for (uint32_t tx = tr.tx0; tx <= tr.tx1; ++tx)
-                    if (owns_tile(tx, ty, fc.rank, fc.world)) atomicAdd(&fb.tile_count[ty * fc.tiles_x + tx], 1u);
+                    if (owns_tile(tx, ty, fc.rank, fc.world)) atomicAdd(&count_multi[ty * fc.tiles_x + tx], 1u);
         }
     }
 }
@@ -356,7 +438,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(FrameBuffers fb, FrameConst
     __syncthreads();
     for (uint32_t base = 0; base < n_tiles; base += 1024u) {
         uint32_t i = base + tid;
-        uint32_t v = i < n_tiles ? fb.tile_count[i] : 0u;
+        uint32_t v = i < n_tiles ? fb.tile_count[i] + fb.tile_count[n_tiles + i] : 0u;
         uint32_t inc = v;
         for (int o = 1; o < 64; o <<= 1) {
             uint32_t up = __shfl_up(inc, o);
@@ -384,17 +466,27 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(FrameBuffers fb, FrameConst
 // --- K2b: scatter record slots into the bins ---------------------------------------------
 __global__ __launch_bounds__(256) void k_bin_fill(FrameBuffers fb, FrameConst fc, Capacities cap) {
     const uint32_t n = min(cap.setup_slots + fb.counters->n_records, cap.records);
-    for (uint32_t r0 = blockIdx.x * 256u; r0 < n; r0 += gridDim.x * 256u) {
-        uint32_t r = r0 + threadIdx.x;
-        bool valid = r < n;
-        TileRect t{0, 0, 0, 0};
-        if (valid) {
-            uint32_t w = fb.tilewords[r];
-            valid = w != kInvalidTileword;
-            t.tx0 = w & 255u; t.ty0 = (w >> 8) & 255u;
-            t.tx1 = t.tx0 + ((w >> 16) & 255u); t.ty1 = t.ty0 + (w >> 24);
+    for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < n; r += gridDim.x * 256u) {
+        const uint2 w = fb.tilewords[r];
+        if (w.x == kInvalidTileword) continue;
+        const uint32_t tx0 = w.x & 255u, ty0 = (w.x >> 8) & 255u;
+        if (!guard(tx0 + ((w.x >> 16) & 255u) < fc.tiles_x && ty0 + (w.x >> 24) < fc.tiles_y, fb.counters, kGuardBin)) continue;
+        if (w.y != kNoBinPos) {
+            // single-tile record: its position was handed out by the count pass
+            const uint32_t tile = ty0 * fc.tiles_x + tx0;
+            const uint32_t idx = fb.tile_offset[tile] + w.y;
+            if (idx < cap.entries) fb.entries[idx] = r;
+        } else {
+            const uint32_t tx1 = tx0 + ((w.x >> 16) & 255u), ty1 = ty0 + (w.x >> 24);
+            for (uint32_t ty = ty0; ty <= ty1; ++ty) {
+                if (!owns_tile(tx0, ty, fc.rank, fc.world)) continue;
+                for (uint32_t tx = tx0; tx <= tx1; ++tx) {
+                    const uint32_t tile = ty * fc.tiles_x + tx;
+                    const uint32_t idx = fb.tile_offset[tile] + fb.tile_count[tile] + atomicAdd(&fb.tile_cursor[tile], 1u);
+                    if (idx < cap.entries) fb.entries[idx] = r;
+                }
+            }
         }
-        bin_wave<1>(valid, t, r, fc, fb.tile_cursor, fb.tile_offset, fb.entries, cap.entries);
     }
 }
 
@@ -487,7 +579,7 @@ __global__ __launch_bounds__(256) void k_raster(FrameBuffers fb, FrameConst fc, 
     const int32_t tile_x1 = min(tile_x0 + (int32_t)kTile, (int32_t)fc.width) - 1;
     const int32_t tile_y1 = min(tile_y0 + (int32_t)kTile, (int32_t)fc.height) - 1;
     for (uint32_t k = tid; k < kTilePixels; k += 256u) s_vis[k] = kClearKey;
-    uint32_t off = fb.tile_offset[tile], n = fb.tile_count[tile];
+    uint32_t off = fb.tile_offset[tile], n = fb.tile_count[tile] + fb.tile_count[fc.tiles_x * fc.tiles_y + tile];
     if (off >= cap.entries) n = 0; else n = min(n, cap.entries - off);
     __syncthreads();
     for (uint32_t b = 0; b < n; b += 256u) {
@@ -496,6 +588,7 @@ __global__ __launch_bounds__(256) void k_raster(FrameBuffers fb, FrameConst fc, 
         uint32_t e = b + tid;
         if (e < n) {
             uint32_t slot = fb.entries[off + e];
+            if (!guard(slot < cap.records, fb.counters, kGuardRaster)) slot = 0;
             SetupRecord r = load_record(fb.records, slot);
             int32_t xmin = min(r.x0, min(r.x1, r.x2)), xmax = max(r.x0, max(r.x1, r.x2));
             int32_t ymin = min(r.y0, min(r.y1, r.y2)), ymax = max(r.y0, max(r.y1, r.y2));
@@ -584,19 +677,31 @@ struct PixelInputs {
     bool lit;               // takes part in the light loop
 };
 
-// vs_main outputs re-derived for the winning triangle of one pixel, and the ambient term
-__device__ __forceinline__ void prepare_pixel(const FrameBuffers& fb, const FrameConst& fc, uint32_t id, uint32_t i,
-                                              uint32_t j, PixelInputs& o) {
-    uint32_t it = find_item(fb.tri_bases, fc.n_items, id);
-    const DrawItem& d = fb.items[it];
+// vs_main outputs re-derived for the winning triangle of one pixel, and the ambient term.
+// `d` is wave-uniform (the caller waterfalls over the items of the wave), so its fields come in
+// through scalar loads; per pixel only the index triple and the three 32-byte vertices are gathered.
+__device__ __forceinline__ void prepare_pixel(const DrawItem& d, const FrameConst& fc, uint32_t id, uint32_t i,
+                                              uint32_t j, PixelInputs& o, FrameCounters* counters) {
     uint32_t t = id - d.tri_base;
-    const uint32_t* ix = d.indices + 3ull * t;
+    if (!guard(t < d.n_tris, counters, kGuardShade)) return;
+    gptr_u32 ix = (gptr_u32)d.indices + 3ull * t;
     uint32_t i0 = ix[0], i1 = ix[1], i2 = ix[2];
-    float4 c0 = fb.clip[d.vert_base + i0], c1 = fb.clip[d.vert_base + i1], c2 = fb.clip[d.vert_base + i2];
+    if (!guard(i0 < d.n_verts && i1 < d.n_verts && i2 < d.n_verts, counters, kGuardShade)) return;
+    gptr_f32x4 vp = (gptr_f32x4)d.verts;
+    const f32x4 a0 = vp[2ull * i0], a1 = vp[2ull * i0 + 1];
+    const f32x4 b0v = vp[2ull * i1], b1v = vp[2ull * i1 + 1];
+    const f32x4 c0v = vp[2ull * i2], c1v = vp[2ull * i2 + 1];
+    rnd_vertex va, vb, vc;
+    va.position[0] = a0.x; va.position[1] = a0.y; va.position[2] = a0.z; va.normal[0] = a0.w; va.normal[1] = a1.x; va.normal[2] = a1.y;
+    vb.position[0] = b0v.x; vb.position[1] = b0v.y; vb.position[2] = b0v.z; vb.normal[0] = b0v.w; vb.normal[1] = b1v.x; vb.normal[2] = b1v.y;
+    vc.position[0] = c0v.x; vc.position[1] = c0v.y; vc.position[2] = c0v.z; vc.normal[0] = c0v.w; vc.normal[1] = c1v.x; vc.normal[2] = c1v.y;
+    const float4 c0 = clip_position(d, fc, va.position[0], va.position[1], va.position[2]);
+    const float4 c1 = clip_position(d, fc, vb.position[0], vb.position[1], vb.position[2]);
+    const float4 c2 = clip_position(d, fc, vc.position[0], vc.position[1], vc.position[2]);
     // perspective-correct barycentrics: 2D homogeneous edge functions in f64
     double x0 = c0.x, y0 = c0.y, w0 = c0.w, x1 = c1.x, y1 = c1.y, w1 = c1.w, x2 = c2.x, y2 = c2.y, w2 = c2.w;
-    double xn = (2.0 * ((double)i + 0.5)) / (double)fc.width - 1.0;
-    double yn = 1.0 - (2.0 * ((double)j + 0.5)) / (double)fc.height;
+    double xn = ((double)i + 0.5) * fc.ndc_step_x - 1.0;
+    double yn = 1.0 - ((double)j + 0.5) * fc.ndc_step_y;
     double e0 = ((y1 * w2 - w1 * y2) * xn + (w1 * x2 - x1 * w2) * yn) + (x1 * y2 - y1 * x2);
     double e1 = ((y2 * w0 - w2 * y0) * xn + (w2 * x0 - x2 * w0) * yn) + (x2 * y0 - y2 * x0);
     double e2 = ((y0 * w1 - w0 * y1) * xn + (w0 * x1 - x0 * w1) * yn) + (x0 * y1 - y0 * x1);
@@ -605,7 +710,6 @@ __device__ __forceinline__ void prepare_pixel(const FrameBuffers& fb, const Fram
     if (!(isfinite(d0) && isfinite(d1) && isfinite(d2))) { d0 = 1.0; d1 = 0.0; d2 = 0.0; }
     const float b0 = (float)d0, b1 = (float)d1, b2 = (float)d2;
     // attributes, interpolated in object space and transformed once
-    const rnd_vertex va = d.verts[i0], vb = d.verts[i1], vc = d.verts[i2];
     float px = (b0 * va.position[0] + b1 * vb.position[0]) + b2 * vc.position[0];
     float py = (b0 * va.position[1] + b1 * vb.position[1]) + b2 * vc.position[1];
     float pz = (b0 * va.position[2] + b1 * vb.position[2]) + b2 * vc.position[2];
@@ -680,7 +784,11 @@ __global__ __launch_bounds__(256) void k_shade(FrameBuffers fb, FrameConst fc) {
     __shared__ uint16_t s_list[kMaxLights];
     __shared__ float s_box[4][6];
     __shared__ uint32_t s_cnt[4];
+    __shared__ uint32_t s_bases[kLdsItems + 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const bool bases_in_lds = fc.n_items <= kLdsItems;
+    if (bases_in_lds)
+        for (uint32_t k = tid; k <= fc.n_items; k += 256u) s_bases[k] = fb.tri_bases[k];
     {
         const uint32_t n_words = fc.n_lights * (uint32_t)(sizeof(GpuLight) / 4);
         const uint32_t* src = reinterpret_cast<const uint32_t*>(fb.lights);
@@ -690,6 +798,7 @@ __global__ __launch_bounds__(256) void k_shade(FrameBuffers fb, FrameConst fc) {
     const TileRef ref = fb.launch_order[blockIdx.x];
     const uint32_t tile_x0 = (ref.tile % fc.tiles_x) * kTile, tile_y0 = (ref.tile / fc.tiles_x) * kTile;
     const unsigned long long* vis = reinterpret_cast<const unsigned long long*>(fb.vis) + (size_t)ref.tile * kTilePixels;
+    __syncthreads();
 
     // phase A: fragment inputs of this lane's four pixels
     PixelInputs px[4];
@@ -703,10 +812,21 @@ __global__ __launch_bounds__(256) void k_shade(FrameBuffers fb, FrameConst fc) {
         key[k] = vis[local];
         uint32_t id = (uint32_t)(key[k] & 0xFFFFFFFFull);
         covered[k] = i < fc.width && j < fc.height && id != RND_NONE;
+        if (covered[k] && !guard(id < fc.n_tris, fb.counters, kGuardShade)) covered[k] = false;
         px[k].lit = false;
         px[k].cr = fc.clear_hdr[0]; px[k].cg = fc.clear_hdr[1]; px[k].cb = fc.clear_hdr[2];
         if (covered[k]) {
-            prepare_pixel(fb, fc, id, i, j, px[k]);
+            uint32_t it = bases_in_lds ? find_item(s_bases, fc.n_items, id) : find_item(fb.tri_bases, fc.n_items, id);
+            // waterfall: one pass per distinct draw item among the wave's pixels (usually one)
+            for (unsigned long long pending = __ballot(true); pending;) {
+                uint32_t cur_s, cur = uniform_pick(it, pending, cur_s);
+                const bool mine = it == cur;
+                pending &= ~__ballot(mine);
+                if (mine) {
+                    const DrawItem d = load_item_uniform(fb.items, cur_s);
+                    prepare_pixel(d, fc, id, i, j, px[k], fb.counters);
+                }
+            }
             if (px[k].lit) {
                 lo[0] = fminf(lo[0], px[k].fx); lo[1] = fminf(lo[1], px[k].fy); lo[2] = fminf(lo[2], px[k].fz);
                 hi[0] = fmaxf(hi[0], px[k].fx); hi[1] = fmaxf(hi[1], px[k].fy); hi[2] = fmaxf(hi[2], px[k].fz);

@@ -137,7 +137,7 @@ void VisualServer::rebuild_tiles() {
     d_launch_order_.ensure(std::max<size_t>(n_owned_, 1));
     if (n_owned_) HIP_CHECK(hipMemcpy(d_launch_order_.ptr, order.data(), n_owned_ * sizeof(TileRef), hipMemcpyHostToDevice));
     const size_t n_tiles = (size_t)tiles_x_ * tiles_y_;
-    d_tile_count_.ensure(n_tiles); d_tile_offset_.ensure(n_tiles); d_tile_cursor_.ensure(n_tiles);
+    d_tile_count_.ensure(2 * n_tiles); d_tile_offset_.ensure(n_tiles); d_tile_cursor_.ensure(n_tiles);
     d_vis_.ensure(n_tiles * kTilePixels);
     d_frame_.ensure((size_t)width_ * height_ * 4);
     if (world_ > 1) d_tiles_.ensure(std::max<size_t>((size_t)n_owned_ * kTilePixels * 4, 4));
@@ -322,6 +322,7 @@ void VisualServer::build_frame(std::vector<DrawItem>& items, std::vector<uint32_
     fc.n_items = (uint32_t)items.size(); fc.n_lights = (uint32_t)lights.size();
     fc.n_tris = (uint32_t)tri_base; fc.n_verts = (uint32_t)vert_base;
     fc.rank = rank_; fc.world = world_;
+    fc.ndc_step_x = 2.0 / (double)width_; fc.ndc_step_y = 2.0 / (double)height_;
 }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -346,7 +347,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     d_vert_bases_.ensure(vert_bases.size()); d_tri_bases_.ensure(tri_bases.size());
     d_lights_.ensure(std::max<size_t>(lights.size(), 1));
     d_clip_.ensure(std::max<size_t>(fc.n_verts, 1));
-    d_records_.ensure(cap_.records); d_tilewords_.ensure(cap_.records);
+    d_records_.ensure(cap_.records); d_tilewords_.ensure(2 * (size_t)cap_.records);
     d_clip_queue_.ensure(cap_.clip_queue);
     d_entries_.ensure(cap_.entries);
     if (world_ > 1) d_tiles_.ensure(std::max<size_t>((size_t)n_owned_ * kTilePixels * 4, 4));
@@ -382,7 +383,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
 
     FrameBuffers fb{};
     fb.items = d_items_.ptr; fb.vert_bases = d_vert_bases_.ptr; fb.tri_bases = d_tri_bases_.ptr; fb.lights = d_lights_.ptr;
-    fb.clip = d_clip_.ptr; fb.records = d_records_.ptr; fb.tilewords = d_tilewords_.ptr; fb.clip_queue = d_clip_queue_.ptr;
+    fb.clip = d_clip_.ptr; fb.records = d_records_.ptr; fb.tilewords = reinterpret_cast<uint2*>(d_tilewords_.ptr); fb.clip_queue = d_clip_queue_.ptr;
     fb.tile_count = d_tile_count_.ptr; fb.tile_offset = d_tile_offset_.ptr; fb.tile_cursor = d_tile_cursor_.ptr;
     fb.entries = d_entries_.ptr; fb.counters = d_counters_.ptr;
     fb.launch_order = d_launch_order_.ptr; fb.n_owned = n_owned_;
@@ -398,7 +399,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     event_next_ = (event_next_ + 1) % kEventSets;
     hipEvent_t* ev_ = es.ev;
     HIP_CHECK(hipMemsetAsync(d_counters_.ptr, 0, sizeof(FrameCounters), stream_));
-    HIP_CHECK(hipMemsetAsync(d_tile_count_.ptr, 0, n_tiles * 4, stream_));
+    HIP_CHECK(hipMemsetAsync(d_tile_count_.ptr, 0, 2 * n_tiles * 4, stream_));
     HIP_CHECK(hipEventRecord(ev_[0], stream_));
     launch_transform(fb, fc, stream_);
     HIP_CHECK(hipEventRecord(ev_[1], stream_));
@@ -433,6 +434,11 @@ void VisualServer::finish() {
         HIP_CHECK(hipStreamSynchronize(stream_));
         frame_pending_ = false;
         const FrameCounters c = *h_counters_;
+        if (c.overflow & ~7u) {
+            char msg[96];
+            std::snprintf(msg, sizeof msg, "internal consistency check failed in a kernel (flags 0x%x)", c.overflow);
+            throw Error(RND_ERR_DEVICE, msg);
+        }
         if (!c.overflow) break;
         // an internal stream was too small: grow it to what the frame asked for and run it again
         if (c.overflow & 1u) clip_records_ = (uint32_t)std::min<uint64_t>((uint64_t)c.n_records + c.n_records / 4 + 4096, 0x7FFFFFF0ull);
