@@ -95,8 +95,8 @@ def algorithmic_bytes(stats, n_visible_tris):
     nrec, nbin, p = stats["n_setup"], stats["n_bin_entries"], stats["n_pixels"]
     return {
         "transform": 12 * nv + 16 * nv,                       # SoA positions in, clip xyzw out
-        "setup": 12 * nt + 16 * nv + 48 * nrec + 4 * nrec,    # indices, each clip position once, records + tile words
-        "bin": 4 * nrec + 4 * nbin,                           # tile words in, bin entries out
+        "setup": 12 * nt + 16 * nv + 48 * nrec + 8 * nt,      # indices, each clip position once, records, (tile word, bin pos) per slot
+        "bin": 8 * nt + 4 * nbin,                             # (tile word, bin pos) per slot in, bin entries out
         "raster": 4 * nbin + 48 * nbin + 8 * p,               # entries + records per bin entry, depth|id out
         "shade": 8 * p + 4 * p + 12 * n_visible_tris + 48 * min(3 * n_visible_tris, nv),   # vis in, rgba8 out, gathers
     }
@@ -189,7 +189,7 @@ def main():
         kernels["scan"] = {"ms": round(mean["scan_ms"], 5)}
         dominant = max(("transform", "setup", "bin", "raster", "shade"), key=lambda k: mean[k + "_ms"])
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes per launch from rocprofv3 PMC passes
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))

@@ -12,6 +12,8 @@
 // The arithmetic that decides coverage and depth is integer or single IEEE f32 operations in a
 // fixed order (compiled with -ffp-contract=off; f32 divide and sqrt are correctly rounded by
 // hipcc's default), as DESIGN.md "Raster rules" states it, so results are reproducible bit for bit.
+#include <cstdlib>
+
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
@@ -779,6 +781,53 @@ __device__ __forceinline__ void add_light(const GpuLight& L, PixelInputs& p) {
     p.cb = p.cb + p.bb * (lb * diff + lb * s8);
 }
 
+#if RND_FAST_SHADE
+// Two fragments per lane through the packed f32 pipe (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32):
+// the same Blinn-Phong terms as add_light with products and sums contracted to FMAs and the
+// colour factors regrouped ((b*c) * ((diff + spec) * intensity)); colour parity is a tolerance.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct PixelPair {
+    f32x2 fx, fy, fz, Nx, Ny, Nz, Vx, Vy, Vz, br, bg, bb, cr, cg, cb;
+    bool lit0, lit1;
+};
+__device__ __forceinline__ f32x2 splat2(float v) { return (f32x2){v, v}; }
+__device__ __forceinline__ f32x2 rsq2(f32x2 v) { return (f32x2){__builtin_amdgcn_rsqf(v.x), __builtin_amdgcn_rsqf(v.y)}; }
+__device__ __forceinline__ f32x2 max0(f32x2 v) { return (f32x2){fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f)}; }
+
+__device__ __forceinline__ void add_light_pair(const GpuLight& L, PixelPair& p) {
+#pragma clang fp contract(fast)
+    f32x2 dx, dy, dz, inten;
+    if (L.kind == RND_LIGHT_DIRECTIONAL) {
+        dx = splat2(L.dir[0]); dy = splat2(L.dir[1]); dz = splat2(L.dir[2]);
+        inten = (f32x2){p.lit0 ? L.color[3] : 0.0f, p.lit1 ? L.color[3] : 0.0f};
+    } else {
+        f32x2 ox = p.fx - splat2(L.pos[0]), oy = p.fy - splat2(L.pos[1]), oz = p.fz - splat2(L.pos[2]);
+        f32x2 d2 = ox * ox + oy * oy + oz * oz;
+        f32x2 inv_d = rsq2(d2);
+        f32x2 dist = d2 * inv_d;
+        const bool in0 = p.lit0 && dist.x <= L.radius, in1 = p.lit1 && dist.y <= L.radius;
+        if (!in0 && !in1) return;
+        f32x2 lin = (splat2(L.radius) - dist) * splat2(L.inv_radius);
+        lin = (f32x2){fminf(fmaxf(lin.x, 0.0f), 1.0f), fminf(fmaxf(lin.y, 0.0f), 1.0f)};
+        f32x2 att = (lin * lin) * (splat2(3.0f) - splat2(2.0f) * lin);
+        inten = splat2(L.color[3]) * att;
+        inten = (f32x2){in0 ? inten.x : 0.0f, in1 ? inten.y : 0.0f};
+        dx = ox * inv_d; dy = oy * inv_d; dz = oz * inv_d;
+    }
+    f32x2 diff = max0(-(p.Nx * dx + p.Ny * dy + p.Nz * dz));
+    f32x2 hx = p.Vx - dx, hy = p.Vy - dy, hz = p.Vz - dz;
+    f32x2 inv_h = rsq2(hx * hx + hy * hy + hz * hz);
+    f32x2 sp = max0((p.Nx * hx + p.Ny * hy + p.Nz * hz) * inv_h);
+    f32x2 s2 = sp * sp, s4 = s2 * s2, s8 = s4 * s4;
+    f32x2 w = (diff + s8) * inten;
+    p.cr += (p.br * splat2(L.color[0])) * w;
+    p.cg += (p.bg * splat2(L.color[1])) * w;
+    p.cb += (p.bb * splat2(L.color[2])) * w;
+}
+#endif
+
+// PPT pixels per lane: a workgroup shades 256*PPT consecutive pixels (8*PPT rows) of one tile.
+template <int PPT>
 __global__ __launch_bounds__(256) void k_shade(FrameBuffers fb, FrameConst fc) {
     __shared__ GpuLight s_lights[kMaxLights];
     __shared__ uint16_t s_list[kMaxLights];
@@ -795,25 +844,26 @@ __global__ __launch_bounds__(256) void k_shade(FrameBuffers fb, FrameConst fc) {
         uint32_t* dst = reinterpret_cast<uint32_t*>(s_lights);
         for (uint32_t k = tid; k < n_words; k += 256u) dst[k] = src[k];
     }
-    const TileRef ref = fb.launch_order[blockIdx.x];
+    const TileRef ref = fb.launch_order[blockIdx.x % fb.n_owned];
+    const uint32_t part = (blockIdx.x / fb.n_owned) * (256u * PPT);     // first tile-local pixel of this workgroup
     const uint32_t tile_x0 = (ref.tile % fc.tiles_x) * kTile, tile_y0 = (ref.tile / fc.tiles_x) * kTile;
     const unsigned long long* vis = reinterpret_cast<const unsigned long long*>(fb.vis) + (size_t)ref.tile * kTilePixels;
     __syncthreads();
 
     // phase A: fragment inputs of this lane's four pixels
-    PixelInputs px[4];
-    unsigned long long key[4];
-    bool covered[4];
+    PixelInputs px[PPT];
+    unsigned long long key[PPT];
+    bool covered[PPT];
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
 #pragma unroll
-    for (uint32_t k = 0; k < 4; ++k) {
-        uint32_t local = k * 256u + tid;
+    for (uint32_t k = 0; k < PPT; ++k) {
+        uint32_t local = part + k * 256u + tid;
         uint32_t i = tile_x0 + (local & (kTile - 1)), j = tile_y0 + (local / kTile);
         key[k] = vis[local];
         uint32_t id = (uint32_t)(key[k] & 0xFFFFFFFFull);
         covered[k] = i < fc.width && j < fc.height && id != RND_NONE;
         if (covered[k] && !guard(id < fc.n_tris, fb.counters, kGuardShade)) covered[k] = false;
-        px[k].lit = false;
+        px[k] = PixelInputs{};
         px[k].cr = fc.clear_hdr[0]; px[k].cg = fc.clear_hdr[1]; px[k].cb = fc.clear_hdr[2];
         if (covered[k]) {
             uint32_t it = bases_in_lds ? find_item(s_bases, fc.n_items, id) : find_item(fb.tri_bases, fc.n_items, id);
@@ -879,16 +929,30 @@ __global__ __launch_bounds__(256) void k_shade(FrameBuffers fb, FrameConst fc) {
     if (keep) s_list[base + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = (uint16_t)tid;
     __syncthreads();
     // phase C: light loop
+#if RND_FAST_SHADE
+    if constexpr (PPT == 2) {
+        PixelPair pp;
+#define RND_PAIR(f) pp.f = (f32x2){px[0].f, px[1].f}
+        RND_PAIR(fx); RND_PAIR(fy); RND_PAIR(fz); RND_PAIR(Nx); RND_PAIR(Ny); RND_PAIR(Nz); RND_PAIR(Vx); RND_PAIR(Vy);
+        RND_PAIR(Vz); RND_PAIR(br); RND_PAIR(bg); RND_PAIR(bb); RND_PAIR(cr); RND_PAIR(cg); RND_PAIR(cb);
+#undef RND_PAIR
+        pp.lit0 = px[0].lit; pp.lit1 = px[1].lit;
+        if (__ballot(pp.lit0 || pp.lit1))
+            for (uint32_t li = 0; li < n_list; ++li) add_light_pair(s_lights[s_list[li]], pp);
+        px[0].cr = pp.cr.x; px[0].cg = pp.cg.x; px[0].cb = pp.cb.x;
+        px[1].cr = pp.cr.y; px[1].cg = pp.cg.y; px[1].cb = pp.cb.y;
+    } else
+#endif
     for (uint32_t li = 0; li < n_list; ++li) {
         const GpuLight& L = s_lights[s_list[li]];
 #pragma unroll
-        for (uint32_t k = 0; k < 4; ++k)
+        for (uint32_t k = 0; k < PPT; ++k)
             if (px[k].lit) add_light(L, px[k]);
     }
     // phase D: f16 target, tone map, sRGB (show_texture.wgsl + the sRGB surface)
 #pragma unroll
-    for (uint32_t k = 0; k < 4; ++k) {
-        uint32_t local = k * 256u + tid;
+    for (uint32_t k = 0; k < PPT; ++k) {
+        uint32_t local = part + k * 256u + tid;
         uint32_t i = tile_x0 + (local & (kTile - 1)), j = tile_y0 + (local / kTile);
         bool inside = i < fc.width && j < fc.height;
         float hr = round_f16(px[k].cr), hg = round_f16(px[k].cg), hb = round_f16(px[k].cb);
@@ -991,7 +1055,10 @@ void launch_raster(const FrameBuffers& fb, const FrameConst& fc, const Capacitie
 }
 void launch_shade(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream) {
     if (!fb.n_owned) return;
-    hipLaunchKernelGGL(k_shade, dim3(fb.n_owned), dim3(256), 0, stream, fb, fc);
+    static const int ppt = [] { const char* e = getenv("RND_SHADE_PPT"); int v = e ? atoi(e) : 2; return (v == 1 || v == 2 || v == 4) ? v : 1; }();
+    if (ppt == 4) hipLaunchKernelGGL(k_shade<4>, dim3(fb.n_owned), dim3(256), 0, stream, fb, fc);
+    else if (ppt == 2) hipLaunchKernelGGL(k_shade<2>, dim3(fb.n_owned * 2), dim3(256), 0, stream, fb, fc);
+    else hipLaunchKernelGGL(k_shade<1>, dim3(fb.n_owned * 4), dim3(256), 0, stream, fb, fc);
 }
 void launch_extract(const uint64_t* vis, const TileRef* order, uint32_t n_owned, const FrameConst& fc, float* depth,
                     uint32_t* ids, uint8_t* coverage, hipStream_t stream) {
