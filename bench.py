@@ -94,10 +94,12 @@ def algorithmic_bytes(stats, n_visible_tris):
     nv, nt = stats["n_vertices"], stats["n_triangles"]
     nrec, nbin, p = stats["n_setup"], stats["n_bin_entries"], stats["n_pixels"]
     return {
-        "transform": 12 * nv + 16 * nv,                       # SoA positions in, clip xyzw out
-        "setup": 12 * nt + 16 * nv + 48 * nrec + 8 * nt,      # indices, each clip position once, records, (tile word, bin pos) per slot
-        "bin": 8 * nt + 4 * nbin,                             # (tile word, bin pos) per slot in, bin entries out
-        "raster": 4 * nbin + 48 * nbin + 8 * p,               # entries + records per bin entry, depth|id out
+        "transform": 12 * nv + 16 * nv + 8 * p,               # SoA positions in, clip xyzw out; + the visibility clear timed with it
+        # indices, each clip position once, one 8-byte visibility word per pixel (direct small-triangle
+        # path), and for the triangles that go through the bins a 48-byte record + (tile word, bin pos)
+        "setup": 12 * nt + 16 * nv + 8 * p + 56 * min(nbin, nrec),
+        "bin": 12 * min(nbin, nrec) + 4 * nbin,               # (tile word, bin pos) + tile offset in, bin entries out
+        "raster": 52 * nbin + 16 * min(p, 1024 * nbin),       # entries + records per bin entry, visibility tile in and out
         "shade": 8 * p + 4 * p + 12 * n_visible_tris + 48 * min(3 * n_visible_tris, nv),   # vis in, rgba8 out, gathers
     }
 

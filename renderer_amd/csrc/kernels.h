@@ -22,6 +22,7 @@ struct FrameBuffers {
     SetupRecord* records;
     uint2* tilewords;               // per record: .x = tx0 | ty0<<8 | (w-1)<<16 | (h-1)<<24, .y = position in its bin (single-tile records)
     uint32_t* clip_queue;           // triangle ids that need the clipper
+    uint32_t* chunk_count;          // per k_setup workgroup: [0,C) records it wrote, [C,2C) triangles that survived setup
     uint32_t* tile_count;           // [0,T): single-tile records per tile; [T,2T): multi-tile records per tile
     uint32_t* tile_offset;          // per tile, exclusive scan of tile_count
     uint32_t* tile_cursor;          // per tile, fill cursor of the multi-tile records
@@ -40,6 +41,7 @@ struct FrameBuffers {
 // slots k_setup addresses for n_tris triangles (its workgroups own fixed chunks of the record stream)
 uint32_t setup_slots_for(uint32_t n_tris);
 
+void launch_clear(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream);
 void launch_transform(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream);
 void launch_setup(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream);
 void launch_clip(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream);

@@ -125,6 +125,21 @@ __device__ __forceinline__ float4 clip_position(const DrawItem& d, const FrameCo
 // The draw item is made wave-uniform (waterfall over the rare waves that straddle two items) so
 // its matrices come in through scalar loads.
 // ------------------------------------------------------------------------------------------
+// Frame clear: visibility words of the owned tiles to (depth 1.0, no triangle), tile counts and
+// frame counters to zero.  One workgroup per owned tile.
+__global__ __launch_bounds__(256) void k_clear(FrameBuffers fb, FrameConst fc) {
+    if (blockIdx.x < fb.n_owned) {
+        const uint32_t tile = fb.launch_order[blockIdx.x].tile;
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        u64x2* dst = reinterpret_cast<u64x2*>(fb.vis + (size_t)tile * kTilePixels);
+        const u64x2 clear = {kClearKey, kClearKey};
+        for (uint32_t k = threadIdx.x; k < kTilePixels / 2; k += 256u) dst[k] = clear;
+    }
+    const uint32_t n_counts = 2u * fc.tiles_x * fc.tiles_y;
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n_counts; k += gridDim.x * 256u) fb.tile_count[k] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < sizeof(FrameCounters) / 4) reinterpret_cast<uint32_t*>(fb.counters)[threadIdx.x] = 0;
+}
+
 __global__ __launch_bounds__(256) void k_transform(const DrawItem* __restrict__ items,
                                                    const uint32_t* __restrict__ vert_bases, FrameConst fc,
                                                    float4* __restrict__ clip) {
@@ -163,7 +178,10 @@ __device__ __forceinline__ bool snap_vertex(float cx, float cy, float cz, float 
     return true;
 }
 
-struct TileRect { uint32_t tx0, ty0, tx1, ty1; };
+struct TileRect {
+    uint32_t tx0, ty0, tx1, ty1;     // tiles touched
+    int32_t i0, i1, j0, j1;          // pixels whose centres lie in the bbox (clamped to the frame)
+};
 
 // Cull + bbox + record of one snapped triangle.  Returns false when nothing can be covered.
 __device__ __forceinline__ bool make_record(const Snapped& a, const Snapped& b, const Snapped& c,
@@ -187,6 +205,7 @@ __device__ __forceinline__ bool make_record(const Snapped& a, const Snapped& b, 
     r.flags = ((xmax - xmin) < (1 << 14) && (ymax - ymin) < (1 << 14)) ? 1u : 0u;
     tr.tx0 = (uint32_t)i0 / kTile; tr.tx1 = (uint32_t)i1 / kTile;
     tr.ty0 = (uint32_t)j0 / kTile; tr.ty1 = (uint32_t)j1 / kTile;
+    tr.i0 = i0; tr.i1 = i1; tr.j0 = j0; tr.j1 = j1;
     return true;
 }
 
@@ -201,6 +220,65 @@ __device__ __forceinline__ bool any_owned(const TileRect& t, const FrameConst& f
     for (uint32_t ty = t.ty0; ty <= t.ty1; ++ty)
         if (owns_tile(t.tx0, ty, fc.rank, fc.world)) return true;
     return false;
+}
+
+constexpr uint32_t kSmallPixels = 16;
+
+// fragment sinks: where a covered sample's (depth, triangle id) key is min-resolved
+struct LdsSink {
+    unsigned long long* s_vis;
+    int32_t tile_x0, tile_y0;
+    __device__ __forceinline__ void operator()(int32_t i, int32_t j, float z, uint32_t id) const {
+        z = fminf(fmaxf(z, 0.0f), 1.0f);
+        if (z < 1.0f) {
+            unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | id;
+            atomicMin(&s_vis[(uint32_t)((j - tile_y0) * (int32_t)kTile + (i - tile_x0))], key);
+        }
+    }
+};
+
+// straight into the tile-major visibility buffer in HBM (no-return 64-bit min at the L2): the
+// path of the triangles that cover a handful of pixels, which never enter a bin
+struct GlobalSink {
+    unsigned long long* vis;
+    uint32_t tiles_x, rank, world;
+    __device__ __forceinline__ void operator()(int32_t i, int32_t j, float z, uint32_t id) const {
+        z = fminf(fmaxf(z, 0.0f), 1.0f);
+        const uint32_t tx = (uint32_t)i / kTile, ty = (uint32_t)j / kTile;
+        if (z < 1.0f && owns_tile(tx, ty, rank, world)) {
+            unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | id;
+            const size_t at = (size_t)(ty * tiles_x + tx) * kTilePixels + (((uint32_t)j % kTile) * kTile + ((uint32_t)i % kTile));
+            __hip_atomic_fetch_min(&vis[at], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+};
+
+template <class Sink>
+__device__ __forceinline__ void raster_small(const SetupRecord& r, int32_t i0, int32_t i1, int32_t j0, int32_t j1,
+                                             const Sink& sink) {
+    // inside-positive edges: w0 = F(v2,v1,p), w1 = F(v0,v2,p), w2 = F(v1,v0,p)
+    const int32_t ex0 = r.x1 - r.x2, ey0 = r.y1 - r.y2;
+    const int32_t ex1 = r.x2 - r.x0, ey1 = r.y2 - r.y0;
+    const int32_t ex2 = r.x0 - r.x1, ey2 = r.y0 - r.y1;
+    const int32_t b0 = ((-ey0 > 0) || (ey0 == 0 && ex0 > 0)) ? 0 : 1;
+    const int32_t b1 = ((-ey1 > 0) || (ey1 == 0 && ex1 > 0)) ? 0 : 1;
+    const int32_t b2 = ((-ey2 > 0) || (ey2 == 0 && ex2 > 0)) ? 0 : 1;
+    const int32_t px = i0 * kSub + kSub / 2, py = j0 * kSub + kSub / 2;
+    int32_t r0 = ex0 * (py - r.y2) - ey0 * (px - r.x2);
+    int32_t r1 = ex1 * (py - r.y0) - ey1 * (px - r.x0);
+    int32_t r2 = ex2 * (py - r.y1) - ey2 * (px - r.x1);
+    for (int32_t j = j0; j <= j1; ++j) {
+        int32_t w0 = r0, w1 = r1, w2 = r2;
+        for (int32_t i = i0; i <= i1; ++i) {
+            if (w0 >= b0 && w1 >= b1 && w2 >= b2) {
+                float l1 = (float)w1 * r.inv_area, l2 = (float)w2 * r.inv_area;
+                float z = (l1 * r.dz1 + l2 * r.dz2) + r.z0;
+                sink(i, j, z, r.tri_id);
+            }
+            w0 -= ey0 * kSub; w1 -= ey1 * kSub; w2 -= ey2 * kSub;
+        }
+        r0 += ex0 * kSub; r1 += ex1 * kSub; r2 += ex2 * kSub;
+    }
 }
 
 // Adds this wave's records to the per-tile counts.  Records that touch ONE tile (the bulk) are
@@ -267,15 +345,18 @@ __device__ __forceinline__ void setup_triangle(const float4& c0, const float4& c
     if (ok0 && ok1 && ok2) emit = make_record(s0, s1, s2, gid, fc, rec, tr) && any_owned(tr, fc);
 }
 
+// A triangle whose bbox holds at most kSmallPixels pixel centres (the bulk at C2..C5 density) is
+// rasterized right here by its lane, straight into the visibility buffer (GlobalSink); only the
+// larger ones become records and go through the bins to the per-tile raster kernel.
 // Slots of the record stream are deterministic: workgroup b owns slots [b*kSetupChunk,
-// (b+1)*kSetupChunk) and fills them densely from the front with a ballot + LDS prefix over its
-// waves; the unused tail gets an invalid tile word.  No global counter sits on this path (one
+// (b+1)*kSetupChunk), fills them densely from the front with a ballot + LDS prefix over its
+// waves and leaves the number it used in chunk_count[b].  No global counter sits on this path (one
 // word takes ~88 atomics/us on MI355X: 10M triangles / 64 lanes on one counter cost 1.4 ms here).
 constexpr uint32_t kSetupChunk = 2048;
-constexpr uint32_t kInvalidTileword = 0xFFFFFFFFu;
 
 __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, FrameConst fc, Capacities cap) {
     __shared__ uint32_t s_wave_cnt[2][4];
+    __shared__ uint32_t s_valid[4];
     __shared__ uint32_t s_bases[kLdsItems + 1];
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     const bool bases_in_lds = fc.n_items <= kLdsItems;
@@ -286,12 +367,13 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, FrameConst fc, C
     const uint32_t chunk_base = blockIdx.x * kSetupChunk;
     const float half_w = 0.5f * (float)fc.width, half_h = 0.5f * (float)fc.height;
     const uint32_t n_tiles = fc.tiles_x * fc.tiles_y;
-    uint32_t running = 0;
+    const GlobalSink direct_sink{reinterpret_cast<unsigned long long*>(fb.vis), fc.tiles_x, fc.rank, fc.world};
+    uint32_t running = 0, valid = 0;
     for (uint32_t iter = 0; iter < kSetupChunk / 256u; ++iter) {
         const uint32_t gid = chunk_base + iter * 256u + threadIdx.x;
         bool emit = false, need_clip = false;
         SetupRecord rec;
-        TileRect tr{0, 0, 0, 0};
+        TileRect tr{0, 0, 0, 0, 0, 0, 0, 0};
         if (gid < fc.n_tris) {
             uint32_t it = bases_in_lds ? find_item(s_bases, fc.n_items, gid) : find_item(fb.tri_bases, fc.n_items, gid);
             // waterfall over the (at most a few) draw items a wave's triangles belong to
@@ -331,7 +413,14 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, FrameConst fc, C
                 if (q < cap.clip_queue) fb.clip_queue[q] = gid; else atomicOr(&fb.counters->overflow, 2u);
             }
         }
-        // workgroup-compacted record stream
+        valid += (uint32_t)__popcll(__ballot(emit));
+        // small triangles: rasterize now, no record
+        if (emit && (rec.flags & 1u) &&
+            (uint32_t)(tr.i1 - tr.i0 + 1) * (uint32_t)(tr.j1 - tr.j0 + 1) <= kSmallPixels) {
+            raster_small(rec, tr.i0, tr.i1, tr.j0, tr.j1, direct_sink);
+            emit = false;
+        }
+        // workgroup-compacted record stream of the rest
         unsigned long long em = __ballot(emit);
         if (lane == 0) s_wave_cnt[iter & 1u][wave] = (uint32_t)__popcll(em);
         __syncthreads();
@@ -351,8 +440,12 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, FrameConst fc, C
             fb.tilewords[slot] = make_uint2(pack_tileword(tr), pos);
         }
     }
-    for (uint32_t k = running + threadIdx.x; k < kSetupChunk; k += 256u) fb.tilewords[chunk_base + k] = make_uint2(kInvalidTileword, kNoBinPos);
-    if (threadIdx.x == 0 && running) atomicAdd(&fb.counters->n_valid, running);
+    if (lane == 0) s_valid[wave] = valid;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        fb.chunk_count[blockIdx.x] = running;
+        fb.chunk_count[gridDim.x + blockIdx.x] = s_valid[0] + s_valid[1] + s_valid[2] + s_valid[3];
+    }
 }
 
 // --- clipper (rare path): near, far and the four guard-band planes, then a fan -------------
@@ -459,36 +552,60 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(FrameBuffers fb, FrameConst
         if (tid == 1023) s_carry = carry + wave_off + inc;
         __syncthreads();
     }
+    // statistics: triangles that survived setup (per-chunk counts of k_setup + the clipper's)
+    const uint32_t n_chunks = cap.setup_slots / kSetupChunk;
+    uint32_t v = 0;
+    for (uint32_t c = tid; c < n_chunks; c += 1024u) v += fb.chunk_count[n_chunks + c];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if (lane == 0) s_wave[wave] = v;
+    __syncthreads();
     if (tid == 0) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < 16; ++w) total += s_wave[w];
+        atomicAdd(&fb.counters->n_valid, total);
         fb.counters->n_entries = s_carry;
         if (s_carry > cap.entries) atomicOr(&fb.counters->overflow, 4u);
     }
 }
 
 // --- K2b: scatter record slots into the bins ---------------------------------------------
-__global__ __launch_bounds__(256) void k_bin_fill(FrameBuffers fb, FrameConst fc, Capacities cap) {
-    const uint32_t n = min(cap.setup_slots + fb.counters->n_records, cap.records);
-    for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < n; r += gridDim.x * 256u) {
-        const uint2 w = fb.tilewords[r];
-        if (w.x == kInvalidTileword) continue;
-        const uint32_t tx0 = w.x & 255u, ty0 = (w.x >> 8) & 255u;
-        if (!guard(tx0 + ((w.x >> 16) & 255u) < fc.tiles_x && ty0 + (w.x >> 24) < fc.tiles_y, fb.counters, kGuardBin)) continue;
-        if (w.y != kNoBinPos) {
-            // single-tile record: its position was handed out by the count pass
-            const uint32_t tile = ty0 * fc.tiles_x + tx0;
-            const uint32_t idx = fb.tile_offset[tile] + w.y;
-            if (idx < cap.entries) fb.entries[idx] = r;
-        } else {
-            const uint32_t tx1 = tx0 + ((w.x >> 16) & 255u), ty1 = ty0 + (w.x >> 24);
-            for (uint32_t ty = ty0; ty <= ty1; ++ty) {
-                if (!owns_tile(tx0, ty, fc.rank, fc.world)) continue;
-                for (uint32_t tx = tx0; tx <= tx1; ++tx) {
-                    const uint32_t tile = ty * fc.tiles_x + tx;
-                    const uint32_t idx = fb.tile_offset[tile] + fb.tile_count[tile] + atomicAdd(&fb.tile_cursor[tile], 1u);
-                    if (idx < cap.entries) fb.entries[idx] = r;
-                }
+__device__ __forceinline__ void bin_record(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, uint32_t r) {
+    const uint2 w = fb.tilewords[r];
+    const uint32_t tx0 = w.x & 255u, ty0 = (w.x >> 8) & 255u;
+    if (!guard(tx0 + ((w.x >> 16) & 255u) < fc.tiles_x && ty0 + (w.x >> 24) < fc.tiles_y, fb.counters, kGuardBin)) return;
+    if (w.y != kNoBinPos) {
+        // single-tile record: its position was handed out by the count pass
+        const uint32_t tile = ty0 * fc.tiles_x + tx0;
+        const uint32_t idx = fb.tile_offset[tile] + w.y;
+        if (idx < cap.entries) fb.entries[idx] = r;
+    } else {
+        const uint32_t tx1 = tx0 + ((w.x >> 16) & 255u), ty1 = ty0 + (w.x >> 24);
+        for (uint32_t ty = ty0; ty <= ty1; ++ty) {
+            if (!owns_tile(tx0, ty, fc.rank, fc.world)) continue;
+            for (uint32_t tx = tx0; tx <= tx1; ++tx) {
+                const uint32_t tile = ty * fc.tiles_x + tx;
+                const uint32_t idx = fb.tile_offset[tile] + fb.tile_count[tile] + atomicAdd(&fb.tile_cursor[tile], 1u);
+                if (idx < cap.entries) fb.entries[idx] = r;
             }
         }
+    }
+}
+
+// Workgroup b < n_chunks takes the records k_setup's workgroup b left at the front of its chunk;
+// the remaining workgroups stride over the clipper's records behind the deterministic slots.
+constexpr uint32_t kBinClipBlocks = 64;
+
+__global__ __launch_bounds__(256) void k_bin_fill(FrameBuffers fb, FrameConst fc, Capacities cap) {
+    const uint32_t n_chunks = cap.setup_slots / kSetupChunk;
+    if (blockIdx.x < n_chunks) {
+        const uint32_t base = blockIdx.x * kSetupChunk;
+        const uint32_t n = min(fb.chunk_count[blockIdx.x], kSetupChunk);
+        for (uint32_t k = threadIdx.x; k < n; k += 256u) bin_record(fb, fc, cap, base + k);
+    } else {
+        const uint32_t n = min(cap.setup_slots + fb.counters->n_records, cap.records);
+        for (uint32_t r = cap.setup_slots + (blockIdx.x - n_chunks) * 256u + threadIdx.x; r < n; r += kBinClipBlocks * 256u)
+            bin_record(fb, fc, cap, r);
     }
 }
 
@@ -500,45 +617,8 @@ __global__ __launch_bounds__(256) void k_bin_fill(FrameBuffers fb, FrameConst fc
 // lane each with 32-bit edge functions; the rest are queued in LDS and swept by a whole wave in
 // 8x8 pixel blocks with 64-bit edge functions.
 // ------------------------------------------------------------------------------------------
-constexpr uint32_t kSmallPixels = 16;
-
-__device__ __forceinline__ void resolve(unsigned long long* s_vis, uint32_t local, float z, uint32_t id) {
-    z = fminf(fmaxf(z, 0.0f), 1.0f);
-    if (z < 1.0f) {
-        unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | id;
-        atomicMin(&s_vis[local], key);
-    }
-}
-
-__device__ __forceinline__ void raster_small(const SetupRecord& r, int32_t i0, int32_t i1, int32_t j0, int32_t j1,
-                                             int32_t tile_x0, int32_t tile_y0, unsigned long long* s_vis) {
-    // inside-positive edges: w0 = F(v2,v1,p), w1 = F(v0,v2,p), w2 = F(v1,v0,p)
-    const int32_t ex0 = r.x1 - r.x2, ey0 = r.y1 - r.y2;
-    const int32_t ex1 = r.x2 - r.x0, ey1 = r.y2 - r.y0;
-    const int32_t ex2 = r.x0 - r.x1, ey2 = r.y0 - r.y1;
-    const int32_t b0 = ((-ey0 > 0) || (ey0 == 0 && ex0 > 0)) ? 0 : 1;
-    const int32_t b1 = ((-ey1 > 0) || (ey1 == 0 && ex1 > 0)) ? 0 : 1;
-    const int32_t b2 = ((-ey2 > 0) || (ey2 == 0 && ex2 > 0)) ? 0 : 1;
-    const int32_t px = i0 * kSub + kSub / 2, py = j0 * kSub + kSub / 2;
-    int32_t r0 = ex0 * (py - r.y2) - ey0 * (px - r.x2);
-    int32_t r1 = ex1 * (py - r.y0) - ey1 * (px - r.x0);
-    int32_t r2 = ex2 * (py - r.y1) - ey2 * (px - r.x1);
-    for (int32_t j = j0; j <= j1; ++j) {
-        int32_t w0 = r0, w1 = r1, w2 = r2;
-        for (int32_t i = i0; i <= i1; ++i) {
-            if (w0 >= b0 && w1 >= b1 && w2 >= b2) {
-                float l1 = (float)w1 * r.inv_area, l2 = (float)w2 * r.inv_area;
-                float z = (l1 * r.dz1 + l2 * r.dz2) + r.z0;
-                resolve(s_vis, (uint32_t)((j - tile_y0) * (int32_t)kTile + (i - tile_x0)), z, r.tri_id);
-            }
-            w0 -= ey0 * kSub; w1 -= ey1 * kSub; w2 -= ey2 * kSub;
-        }
-        r0 += ex0 * kSub; r1 += ex1 * kSub; r2 += ex2 * kSub;
-    }
-}
-
 __device__ __forceinline__ void raster_wave(const SetupRecord& r, int32_t i0, int32_t i1, int32_t j0, int32_t j1,
-                                            int32_t tile_x0, int32_t tile_y0, unsigned long long* s_vis) {
+                                            const LdsSink& sink) {
     const uint32_t lane = lane_id();
     const int32_t lx = (int32_t)(lane & 7u), ly = (int32_t)(lane >> 3);
     const int32_t ex0 = r.x1 - r.x2, ey0 = r.y1 - r.y2;
@@ -558,7 +638,7 @@ __device__ __forceinline__ void raster_wave(const SetupRecord& r, int32_t i0, in
             if (w0 >= b0 && w1 >= b1 && w2 >= b2) {
                 float l1 = (float)w1 * r.inv_area, l2 = (float)w2 * r.inv_area;
                 float z = (l1 * r.dz1 + l2 * r.dz2) + r.z0;
-                resolve(s_vis, (uint32_t)((j - tile_y0) * (int32_t)kTile + (i - tile_x0)), z, r.tri_id);
+                sink(i, j, z, r.tri_id);
             }
         }
 }
@@ -580,9 +660,12 @@ __global__ __launch_bounds__(256) void k_raster(FrameBuffers fb, FrameConst fc, 
     const int32_t tile_x0 = (int32_t)((tile % fc.tiles_x) * kTile), tile_y0 = (int32_t)((tile / fc.tiles_x) * kTile);
     const int32_t tile_x1 = min(tile_x0 + (int32_t)kTile, (int32_t)fc.width) - 1;
     const int32_t tile_y1 = min(tile_y0 + (int32_t)kTile, (int32_t)fc.height) - 1;
-    for (uint32_t k = tid; k < kTilePixels; k += 256u) s_vis[k] = kClearKey;
     uint32_t off = fb.tile_offset[tile], n = fb.tile_count[tile] + fb.tile_count[fc.tiles_x * fc.tiles_y + tile];
     if (off >= cap.entries) n = 0; else n = min(n, cap.entries - off);
+    if (n == 0) return;     // nothing binned here: the tile keeps what k_setup's direct path wrote
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(fb.vis) + (size_t)tile * kTilePixels;
+    for (uint32_t k = tid; k < kTilePixels; k += 256u) s_vis[k] = dst[k];
+    const LdsSink sink{s_vis, tile_x0, tile_y0};
     __syncthreads();
     for (uint32_t b = 0; b < n; b += 256u) {
         if (tid == 0) s_nbig = 0;
@@ -600,7 +683,7 @@ __global__ __launch_bounds__(256) void k_raster(FrameBuffers fb, FrameConst fc, 
             int32_t j1 = min((ymax - kSub / 2) >> kSubpixelBits, tile_y1);
             if (i0 <= i1 && j0 <= j1) {
                 uint32_t npix = (uint32_t)(i1 - i0 + 1) * (uint32_t)(j1 - j0 + 1);
-                if ((r.flags & 1u) && npix <= kSmallPixels) raster_small(r, i0, i1, j0, j1, tile_x0, tile_y0, s_vis);
+                if ((r.flags & 1u) && npix <= kSmallPixels) raster_small(r, i0, i1, j0, j1, sink);
                 else s_big[atomicAdd(&s_nbig, 1u)] = slot;
             }
         }
@@ -614,11 +697,10 @@ __global__ __launch_bounds__(256) void k_raster(FrameBuffers fb, FrameConst fc, 
             int32_t i1 = min((xmax - kSub / 2) >> kSubpixelBits, tile_x1);
             int32_t j0 = max((ymin - kSub / 2 + kSub - 1) >> kSubpixelBits, tile_y0);
             int32_t j1 = min((ymax - kSub / 2) >> kSubpixelBits, tile_y1);
-            raster_wave(r, i0, i1, j0, j1, tile_x0, tile_y0, s_vis);
+            raster_wave(r, i0, i1, j0, j1, sink);
         }
         __syncthreads();
     }
-    unsigned long long* dst = reinterpret_cast<unsigned long long*>(fb.vis) + (size_t)tile * kTilePixels;
     for (uint32_t k = tid; k < kTilePixels; k += 256u) dst[k] = s_vis[k];
 }
 
@@ -1028,6 +1110,10 @@ __global__ void k_unpack(const unsigned long long* __restrict__ packed, FrameCon
 // ------------------------------------------------------------------------------------------
 static inline uint32_t div_up(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
 
+void launch_clear(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream) {
+    hipLaunchKernelGGL(k_clear, dim3(fb.n_owned ? fb.n_owned : 1u), dim3(256), 0, stream, fb, fc);
+}
+
 void launch_transform(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream) {
     if (!fc.n_verts) return;
     hipLaunchKernelGGL(k_transform, dim3(div_up(fc.n_verts, 256)), dim3(256), 0, stream, fb.items, fb.vert_bases, fc, fb.clip);
@@ -1046,7 +1132,7 @@ void launch_scan(const FrameBuffers& fb, const FrameConst& fc, const Capacities&
 }
 void launch_bin(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {
     if (!fc.n_tris) return;
-    uint32_t blocks = min(div_up(cap.records, 256), 4096u);
+    uint32_t blocks = cap.setup_slots / kSetupChunk + kBinClipBlocks;
     hipLaunchKernelGGL(k_bin_fill, dim3(blocks), dim3(256), 0, stream, fb, fc, cap);
 }
 void launch_raster(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {

@@ -70,7 +70,7 @@ VisualServer::~VisualServer() {
     for (auto& kv : meshes_)
         for (auto& s : kv.second.submeshes) { s.vertex_buffer.release(); s.positions.release(); s.index_buffer.release(); }
     d_items_.release(); d_vert_bases_.release(); d_tri_bases_.release(); d_lights_.release(); d_clip_.release();
-    d_records_.release(); d_tilewords_.release(); d_clip_queue_.release(); d_tile_count_.release();
+    d_records_.release(); d_tilewords_.release(); d_clip_queue_.release(); d_chunk_count_.release(); d_tile_count_.release();
     d_tile_offset_.release(); d_tile_cursor_.release(); d_entries_.release(); d_counters_.release();
     d_launch_order_.release(); d_vis_.release(); d_frame_.release(); d_tiles_.release(); d_packed_.release();
     d_hdr_.release();
@@ -349,6 +349,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     d_clip_.ensure(std::max<size_t>(fc.n_verts, 1));
     d_records_.ensure(cap_.records); d_tilewords_.ensure(2 * (size_t)cap_.records);
     d_clip_queue_.ensure(cap_.clip_queue);
+    d_chunk_count_.ensure(std::max<size_t>(2 * (size_t)(cap_.setup_slots / 2048u), 2));
     d_entries_.ensure(cap_.entries);
     if (world_ > 1) d_tiles_.ensure(std::max<size_t>((size_t)n_owned_ * kTilePixels * 4, 4));
     if (want_packed_) d_packed_.ensure((size_t)width_ * height_);
@@ -384,6 +385,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     FrameBuffers fb{};
     fb.items = d_items_.ptr; fb.vert_bases = d_vert_bases_.ptr; fb.tri_bases = d_tri_bases_.ptr; fb.lights = d_lights_.ptr;
     fb.clip = d_clip_.ptr; fb.records = d_records_.ptr; fb.tilewords = reinterpret_cast<uint2*>(d_tilewords_.ptr); fb.clip_queue = d_clip_queue_.ptr;
+    fb.chunk_count = d_chunk_count_.ptr;
     fb.tile_count = d_tile_count_.ptr; fb.tile_offset = d_tile_offset_.ptr; fb.tile_cursor = d_tile_cursor_.ptr;
     fb.entries = d_entries_.ptr; fb.counters = d_counters_.ptr;
     fb.launch_order = d_launch_order_.ptr; fb.n_owned = n_owned_;
@@ -398,9 +400,8 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     last_set_ = (int)event_next_;
     event_next_ = (event_next_ + 1) % kEventSets;
     hipEvent_t* ev_ = es.ev;
-    HIP_CHECK(hipMemsetAsync(d_counters_.ptr, 0, sizeof(FrameCounters), stream_));
-    HIP_CHECK(hipMemsetAsync(d_tile_count_.ptr, 0, 2 * n_tiles * 4, stream_));
     HIP_CHECK(hipEventRecord(ev_[0], stream_));
+    launch_clear(fb, fc, stream_);      // visibility words, tile counts, frame counters
     launch_transform(fb, fc, stream_);
     HIP_CHECK(hipEventRecord(ev_[1], stream_));
     launch_setup(fb, fc, cap_, stream_);

@@ -175,7 +175,7 @@ private:
     DeviceBuffer<GpuLight> d_lights_;
     DeviceBuffer<float4> d_clip_;
     DeviceBuffer<SetupRecord> d_records_;
-    DeviceBuffer<uint32_t> d_tilewords_, d_clip_queue_, d_tile_count_, d_tile_offset_, d_tile_cursor_, d_entries_;
+    DeviceBuffer<uint32_t> d_tilewords_, d_clip_queue_, d_chunk_count_, d_tile_count_, d_tile_offset_, d_tile_cursor_, d_entries_;
     DeviceBuffer<FrameCounters> d_counters_;
     DeviceBuffer<TileRef> d_launch_order_;
     DeviceBuffer<uint64_t> d_vis_;
