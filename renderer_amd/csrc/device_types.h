@@ -71,6 +71,7 @@ struct FrameConst {
     uint32_t n_tris, n_verts;
     uint32_t rank, world;
     double ndc_step_x, ndc_step_y;   // 2/width, 2/height in f64 (pixel centre -> NDC at shade time)
+    float ndc_step_xf, ndc_step_yf;  // the same in f32
 };
 
 // Setup record of one (sub-)triangle after cull / clip / snap: 48 bytes.

@@ -752,6 +752,26 @@ __device__ __forceinline__ uint32_t srgb8_f(float lin) {
 #endif
 }
 
+// Monotone map f32 -> u32 (and back) so float min/max run as integer min/max over DPP row
+// rotations: no NaN canonicalization, one instruction per step.
+__device__ __forceinline__ uint32_t f32_ordered(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float f32_from_ordered(uint32_t u) {
+    return __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u);
+}
+// min (or max) over the 64 lanes; every lane must be active.  Result is wave-uniform.
+template <bool kMin>
+__device__ __forceinline__ uint32_t wave_minmax_u32(uint32_t v) {
+#define RND_ROR(n) { const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x120 + n, 0xf, 0xf, false); v = kMin ? min(v, o) : max(v, o); }
+    RND_ROR(1) RND_ROR(2) RND_ROR(4) RND_ROR(8)
+#undef RND_ROR
+    const uint32_t r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+    const uint32_t r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    return kMin ? min(min(r0, r1), min(r2, r3)) : max(max(r0, r1), max(r2, r3));
+}
+
 struct PixelInputs {
     float fx, fy, fz;       // world position (frag_pos)
     float Nx, Ny, Nz;       // normalized normal
@@ -764,8 +784,9 @@ struct PixelInputs {
 // vs_main outputs re-derived for the winning triangle of one pixel, and the ambient term.
 // `d` is wave-uniform (the caller waterfalls over the items of the wave), so its fields come in
 // through scalar loads; per pixel only the index triple and the three 32-byte vertices are gathered.
-__device__ __forceinline__ void prepare_pixel(const DrawItem& d, const FrameConst& fc, uint32_t id, uint32_t i,
-                                              uint32_t j, PixelInputs& o, FrameCounters* counters) {
+__device__ __forceinline__ void prepare_pixel(const DrawItem& d, const FrameConst& fc, const float4* __restrict__ clip,
+                                              uint32_t id, uint32_t i, uint32_t j, PixelInputs& o,
+                                              FrameCounters* counters) {
     uint32_t t = id - d.tri_base;
     if (!guard(t < d.n_tris, counters, kGuardShade)) return;
     gptr_u32 ix = (gptr_u32)d.indices + 3ull * t;
@@ -779,10 +800,27 @@ __device__ __forceinline__ void prepare_pixel(const DrawItem& d, const FrameCons
     va.position[0] = a0.x; va.position[1] = a0.y; va.position[2] = a0.z; va.normal[0] = a0.w; va.normal[1] = a1.x; va.normal[2] = a1.y;
     vb.position[0] = b0v.x; vb.position[1] = b0v.y; vb.position[2] = b0v.z; vb.normal[0] = b0v.w; vb.normal[1] = b1v.x; vb.normal[2] = b1v.y;
     vc.position[0] = c0v.x; vc.position[1] = c0v.y; vc.position[2] = c0v.z; vc.normal[0] = c0v.w; vc.normal[1] = c1v.x; vc.normal[2] = c1v.y;
-    const float4 c0 = clip_position(d, fc, va.position[0], va.position[1], va.position[2]);
-    const float4 c1 = clip_position(d, fc, vb.position[0], vb.position[1], vb.position[2]);
-    const float4 c2 = clip_position(d, fc, vc.position[0], vc.position[1], vc.position[2]);
-    // perspective-correct barycentrics: 2D homogeneous edge functions in f64
+    // the clip positions K1 stored for these vertices (what setup and raster saw)
+    if (!guard(d.vert_base + d.n_verts <= fc.n_verts, counters, kGuardShade)) return;
+    const float4 c0 = clip[d.vert_base + i0], c1 = clip[d.vert_base + i1], c2 = clip[d.vert_base + i2];
+    // perspective-correct barycentrics: 2D homogeneous edge functions of (x, y, w) at the pixel centre
+    // (valid for w <= 0 vertices too)
+#if RND_FAST_SHADE
+    // f32: the triangle is first moved so the pixel centre is the origin (one FMA per coordinate,
+    // so the differences of nearly equal numbers are exact up to the rounding of the centre itself,
+    // ~1e-4 px), then the edge functions are plain 2x2 determinants of small numbers
+    const float xn = fmaf((float)i + 0.5f, fc.ndc_step_xf, -1.0f);
+    const float yn = fmaf(-((float)j + 0.5f), fc.ndc_step_yf, 1.0f);
+    const float xr0 = fmaf(-xn, c0.w, c0.x), yr0 = fmaf(-yn, c0.w, c0.y);
+    const float xr1 = fmaf(-xn, c1.w, c1.x), yr1 = fmaf(-yn, c1.w, c1.y);
+    const float xr2 = fmaf(-xn, c2.w, c2.x), yr2 = fmaf(-yn, c2.w, c2.y);
+    const float e0 = fmaf(xr1, yr2, -(xr2 * yr1));
+    const float e1 = fmaf(xr2, yr0, -(xr0 * yr2));
+    const float e2 = fmaf(xr0, yr1, -(xr1 * yr0));
+    const float inv_s = rcp_f((e0 + e1) + e2);
+    float b0 = e0 * inv_s, b1 = e1 * inv_s, b2 = e2 * inv_s;
+    if (!(fabsf(b0) + fabsf(b1) + fabsf(b2) < 3.0e38f)) { b0 = 1.0f; b1 = 0.0f; b2 = 0.0f; }
+#else
     double x0 = c0.x, y0 = c0.y, w0 = c0.w, x1 = c1.x, y1 = c1.y, w1 = c1.w, x2 = c2.x, y2 = c2.y, w2 = c2.w;
     double xn = ((double)i + 0.5) * fc.ndc_step_x - 1.0;
     double yn = 1.0 - ((double)j + 0.5) * fc.ndc_step_y;
@@ -793,6 +831,7 @@ __device__ __forceinline__ void prepare_pixel(const DrawItem& d, const FrameCons
     double d0 = e0 * inv_s, d1 = e1 * inv_s, d2 = e2 * inv_s;
     if (!(isfinite(d0) && isfinite(d1) && isfinite(d2))) { d0 = 1.0; d1 = 0.0; d2 = 0.0; }
     const float b0 = (float)d0, b1 = (float)d1, b2 = (float)d2;
+#endif
     // attributes, interpolated in object space and transformed once
     float px = (b0 * va.position[0] + b1 * vb.position[0]) + b2 * vc.position[0];
     float py = (b0 * va.position[1] + b1 * vb.position[1]) + b2 * vc.position[1];
@@ -956,7 +995,7 @@ __global__ __launch_bounds__(256) void k_shade(FrameBuffers fb, FrameConst fc) {
                 pending &= ~__ballot(mine);
                 if (mine) {
                     const DrawItem d = load_item_uniform(fb.items, cur_s);
-                    prepare_pixel(d, fc, id, i, j, px[k], fb.counters);
+                    prepare_pixel(d, fc, fb.clip, id, i, j, px[k], fb.counters);
                 }
             }
             if (px[k].lit) {
@@ -969,11 +1008,10 @@ __global__ __launch_bounds__(256) void k_shade(FrameBuffers fb, FrameConst fc) {
     // of the tile's fragments adds exactly zero to every one of them (distance > radius discards),
     // so dropping it changes nothing; the list keeps the lights in their original order.
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-        for (int o = 32; o > 0; o >>= 1) {
-            lo[c] = fminf(lo[c], __shfl_xor(lo[c], o));
-            hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], o));
-        }
+    for (int c = 0; c < 3; ++c) {
+        lo[c] = f32_from_ordered(wave_minmax_u32<true>(f32_ordered(lo[c])));
+        hi[c] = f32_from_ordered(wave_minmax_u32<false>(f32_ordered(hi[c])));
+    }
     if (lane == 0) {
         s_box[wave][0] = lo[0]; s_box[wave][1] = lo[1]; s_box[wave][2] = lo[2];
         s_box[wave][3] = hi[0]; s_box[wave][4] = hi[1]; s_box[wave][5] = hi[2];

@@ -323,6 +323,7 @@ void VisualServer::build_frame(std::vector<DrawItem>& items, std::vector<uint32_
     fc.n_tris = (uint32_t)tri_base; fc.n_verts = (uint32_t)vert_base;
     fc.rank = rank_; fc.world = world_;
     fc.ndc_step_x = 2.0 / (double)width_; fc.ndc_step_y = 2.0 / (double)height_;
+    fc.ndc_step_xf = (float)fc.ndc_step_x; fc.ndc_step_yf = (float)fc.ndc_step_y;
 }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
