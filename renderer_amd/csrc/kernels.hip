@@ -787,11 +787,17 @@ struct PixelInputs {
 __device__ __forceinline__ void prepare_pixel(const DrawItem& d, const FrameConst& fc, const float4* __restrict__ clip,
                                               uint32_t id, uint32_t i, uint32_t j, PixelInputs& o,
                                               FrameCounters* counters) {
+    // straight-line: an index that would leave its buffer is clamped and reported, not branched on
     uint32_t t = id - d.tri_base;
-    if (!guard(t < d.n_tris, counters, kGuardShade)) return;
+    bool ok = t < d.n_tris;
+    t = ok ? t : 0u;
     gptr_u32 ix = (gptr_u32)d.indices + 3ull * t;
     uint32_t i0 = ix[0], i1 = ix[1], i2 = ix[2];
-    if (!guard(i0 < d.n_verts && i1 < d.n_verts && i2 < d.n_verts, counters, kGuardShade)) return;
+    const uint32_t last_v = max(d.n_verts, 1u) - 1u;
+    ok = ok && max(i0, max(i1, i2)) <= last_v && d.n_verts != 0u && d.vert_base + d.n_verts <= fc.n_verts;
+    i0 = min(i0, last_v); i1 = min(i1, last_v); i2 = min(i2, last_v);
+    guard(ok, counters, kGuardShade);
+    const uint32_t last_c = max(fc.n_verts, 1u) - 1u;
     gptr_f32x4 vp = (gptr_f32x4)d.verts;
     const f32x4 a0 = vp[2ull * i0], a1 = vp[2ull * i0 + 1];
     const f32x4 b0v = vp[2ull * i1], b1v = vp[2ull * i1 + 1];
@@ -801,8 +807,8 @@ __device__ __forceinline__ void prepare_pixel(const DrawItem& d, const FrameCons
     vb.position[0] = b0v.x; vb.position[1] = b0v.y; vb.position[2] = b0v.z; vb.normal[0] = b0v.w; vb.normal[1] = b1v.x; vb.normal[2] = b1v.y;
     vc.position[0] = c0v.x; vc.position[1] = c0v.y; vc.position[2] = c0v.z; vc.normal[0] = c0v.w; vc.normal[1] = c1v.x; vc.normal[2] = c1v.y;
     // the clip positions K1 stored for these vertices (what setup and raster saw)
-    if (!guard(d.vert_base + d.n_verts <= fc.n_verts, counters, kGuardShade)) return;
-    const float4 c0 = clip[d.vert_base + i0], c1 = clip[d.vert_base + i1], c2 = clip[d.vert_base + i2];
+    const float4 c0 = clip[min(d.vert_base + i0, last_c)], c1 = clip[min(d.vert_base + i1, last_c)],
+                 c2 = clip[min(d.vert_base + i2, last_c)];
     // perspective-correct barycentrics: 2D homogeneous edge functions of (x, y, w) at the pixel centre
     // (valid for w <= 0 vertices too)
 #if RND_FAST_SHADE
@@ -986,18 +992,30 @@ __global__ __launch_bounds__(256) void k_shade(FrameBuffers fb, FrameConst fc) {
         if (covered[k] && !guard(id < fc.n_tris, fb.counters, kGuardShade)) covered[k] = false;
         px[k] = PixelInputs{};
         px[k].cr = fc.clear_hdr[0]; px[k].cg = fc.clear_hdr[1]; px[k].cb = fc.clear_hdr[2];
-        if (covered[k]) {
-            uint32_t it = bases_in_lds ? find_item(s_bases, fc.n_items, id) : find_item(fb.tri_bases, fc.n_items, id);
-            // waterfall: one pass per distinct draw item among the wave's pixels (usually one)
-            for (unsigned long long pending = __ballot(true); pending;) {
-                uint32_t cur_s, cur = uniform_pick(it, pending, cur_s);
-                const bool mine = it == cur;
-                pending &= ~__ballot(mine);
-                if (mine) {
-                    const DrawItem d = load_item_uniform(fb.items, cur_s);
-                    prepare_pixel(d, fc, fb.clip, id, i, j, px[k], fb.counters);
+        uint32_t it = 0;
+        if (covered[k]) it = bases_in_lds ? find_item(s_bases, fc.n_items, id) : find_item(fb.tri_bases, fc.n_items, id);
+        const unsigned long long cov = __ballot(covered[k]);
+        if (cov) {
+            uint32_t lead_s;
+            const uint32_t lead = uniform_pick(it, cov, lead_s);
+            if (__ballot(covered[k] && it != lead) == 0ull) {
+                // the usual case: every covered pixel of the wave belongs to one draw item
+                const DrawItem d = load_item_uniform(fb.items, lead_s);
+                if (covered[k]) prepare_pixel(d, fc, fb.clip, id, i, j, px[k], fb.counters);
+            } else if (covered[k]) {
+                // waterfall: one pass per distinct draw item among the wave's pixels
+                for (unsigned long long pending = __ballot(true); pending;) {
+                    uint32_t cur_s, cur = uniform_pick(it, pending, cur_s);
+                    const bool mine = it == cur;
+                    pending &= ~__ballot(mine);
+                    if (mine) {
+                        const DrawItem d = load_item_uniform(fb.items, cur_s);
+                        prepare_pixel(d, fc, fb.clip, id, i, j, px[k], fb.counters);
+                    }
                 }
             }
+        }
+        if (covered[k]) {
             if (px[k].lit) {
                 lo[0] = fminf(lo[0], px[k].fx); lo[1] = fminf(lo[1], px[k].fy); lo[2] = fminf(lo[2], px[k].fz);
                 hi[0] = fmaxf(hi[0], px[k].fx); hi[1] = fmaxf(hi[1], px[k].fy); hi[2] = fmaxf(hi[2], px[k].fz);
