@@ -264,9 +264,11 @@ __device__ __forceinline__ void raster_small(const SetupRecord& r, int32_t i0, i
     const int32_t b1 = ((-ey1 > 0) || (ey1 == 0 && ex1 > 0)) ? 0 : 1;
     const int32_t b2 = ((-ey2 > 0) || (ey2 == 0 && ex2 > 0)) ? 0 : 1;
     const int32_t px = i0 * kSub + kSub / 2, py = j0 * kSub + kSub / 2;
-    int32_t r0 = ex0 * (py - r.y2) - ey0 * (px - r.x2);
-    int32_t r1 = ex1 * (py - r.y0) - ey1 * (px - r.x0);
-    int32_t r2 = ex2 * (py - r.y1) - ey2 * (px - r.x1);
+    // callers pass records with flag bit 0 (bbox below 64 px) and pixels of that bbox: every factor
+    // is below 2^15 in magnitude, so the full-rate 24-bit multiply is exact
+    int32_t r0 = __mul24(ex0, py - r.y2) - __mul24(ey0, px - r.x2);
+    int32_t r1 = __mul24(ex1, py - r.y0) - __mul24(ey1, px - r.x0);
+    int32_t r2 = __mul24(ex2, py - r.y1) - __mul24(ey2, px - r.x1);
     for (int32_t j = j0; j <= j1; ++j) {
         int32_t w0 = r0, w1 = r1, w2 = r2;
         for (int32_t i = i0; i <= i1; ++i) {
@@ -328,15 +330,24 @@ __device__ __forceinline__ void setup_triangle(const float4& c0, const float4& c
     bool finite = isfinite(c0.x) && isfinite(c0.y) && isfinite(c0.z) && isfinite(c0.w) &&
                   isfinite(c1.x) && isfinite(c1.y) && isfinite(c1.z) && isfinite(c1.w) &&
                   isfinite(c2.x) && isfinite(c2.y) && isfinite(c2.z) && isfinite(c2.w);
-    // trivial reject against the view volume
-    bool out = (c0.x < -c0.w && c1.x < -c1.w && c2.x < -c2.w) || (c0.x > c0.w && c1.x > c1.w && c2.x > c2.w) ||
-               (c0.y < -c0.w && c1.y < -c1.w && c2.y < -c2.w) || (c0.y > c0.w && c1.y > c1.w && c2.y > c2.w) ||
-               (c0.z < 0.0f && c1.z < 0.0f && c2.z < 0.0f) || (c0.z > c0.w && c1.z > c1.w && c2.z > c2.w);
-    if (!finite || out) return;
-    float g0 = kGuardBand * c0.w, g1 = kGuardBand * c1.w, g2 = kGuardBand * c2.w;
-    need_clip = (c0.z < 0.0f) | (c0.z > c0.w) | (c0.x < -g0) | (c0.x > g0) | (c0.y < -g0) | (c0.y > g0) |
-                (c1.z < 0.0f) | (c1.z > c1.w) | (c1.x < -g1) | (c1.x > g1) | (c1.y < -g1) | (c1.y > g1) |
-                (c2.z < 0.0f) | (c2.z > c2.w) | (c2.x < -g2) | (c2.x > g2) | (c2.y < -g2) | (c2.y > g2);
+    if (!finite) return;
+    // Trivial reject against the view volume and the "needs the clipper" test.  For finite a, b the
+    // rounded sum a + b has the sign of the exact sum (and is zero only if that is), so
+    // x < -w  <=>  x + w < 0 and x > w  <=>  w - x < 0; "all three outside" is then a max3 below zero
+    // and "any outside" a min3 below zero.  (kGuardBand is a power of two: kGuardBand * w is exact.)
+    const float xl0 = c0.x + c0.w, xl1 = c1.x + c1.w, xl2 = c2.x + c2.w;      // >= 0 inside the left plane
+    const float xr0 = c0.w - c0.x, xr1 = c1.w - c1.x, xr2 = c2.w - c2.x;
+    const float yl0 = c0.y + c0.w, yl1 = c1.y + c1.w, yl2 = c2.y + c2.w;
+    const float yr0 = c0.w - c0.y, yr1 = c1.w - c1.y, yr2 = c2.w - c2.y;
+    const float zf0 = c0.w - c0.z, zf1 = c1.w - c1.z, zf2 = c2.w - c2.z;      // >= 0 in front of the far plane
+    const bool out = fmaxf(fmaxf(xl0, xl1), xl2) < 0.0f || fmaxf(fmaxf(xr0, xr1), xr2) < 0.0f ||
+                     fmaxf(fmaxf(yl0, yl1), yl2) < 0.0f || fmaxf(fmaxf(yr0, yr1), yr2) < 0.0f ||
+                     fmaxf(fmaxf(c0.z, c1.z), c2.z) < 0.0f || fmaxf(fmaxf(zf0, zf1), zf2) < 0.0f;
+    if (out) return;
+    const float g0 = kGuardBand * c0.w, g1 = kGuardBand * c1.w, g2 = kGuardBand * c2.w;
+    need_clip = fminf(fminf(c0.z, c1.z), c2.z) < 0.0f || fminf(fminf(zf0, zf1), zf2) < 0.0f ||
+                fminf(fminf(c0.x + g0, c1.x + g1), c2.x + g2) < 0.0f || fminf(fminf(g0 - c0.x, g1 - c1.x), g2 - c2.x) < 0.0f ||
+                fminf(fminf(c0.y + g0, c1.y + g1), c2.y + g2) < 0.0f || fminf(fminf(g0 - c0.y, g1 - c1.y), g2 - c2.y) < 0.0f;
     if (need_clip) return;
     Snapped s0, s1, s2;
     bool ok0 = snap_vertex(c0.x, c0.y, c0.z, c0.w, half_w, half_h, s0);
@@ -355,49 +366,55 @@ __device__ __forceinline__ void setup_triangle(const float4& c0, const float4& c
 constexpr uint32_t kSetupChunk = 2048;
 
 __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, FrameConst fc, Capacities cap) {
-    __shared__ uint32_t s_wave_cnt[2][4];
+    __shared__ uint32_t s_used;         // record slots of this workgroup's chunk handed out so far
     __shared__ uint32_t s_valid[4];
     __shared__ uint32_t s_bases[kLdsItems + 1];
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     const bool bases_in_lds = fc.n_items <= kLdsItems;
-    if (bases_in_lds) {
+    if (bases_in_lds)
         for (uint32_t k = threadIdx.x; k <= fc.n_items; k += 256u) s_bases[k] = fb.tri_bases[k];
-        __syncthreads();
-    }
+    if (threadIdx.x == 0) s_used = 0;
+    __syncthreads();
     const uint32_t chunk_base = blockIdx.x * kSetupChunk;
     const float half_w = 0.5f * (float)fc.width, half_h = 0.5f * (float)fc.height;
     const uint32_t n_tiles = fc.tiles_x * fc.tiles_y;
     const GlobalSink direct_sink{reinterpret_cast<unsigned long long*>(fb.vis), fc.tiles_x, fc.rank, fc.world};
-    uint32_t running = 0, valid = 0;
+    uint32_t valid = 0;
     for (uint32_t iter = 0; iter < kSetupChunk / 256u; ++iter) {
         const uint32_t gid = chunk_base + iter * 256u + threadIdx.x;
         bool emit = false, need_clip = false;
         SetupRecord rec;
         TileRect tr{0, 0, 0, 0, 0, 0, 0, 0};
         if (gid < fc.n_tris) {
-            uint32_t it = bases_in_lds ? find_item(s_bases, fc.n_items, gid) : find_item(fb.tri_bases, fc.n_items, gid);
-            // waterfall over the (at most a few) draw items a wave's triangles belong to
-            for (unsigned long long pending = __ballot(true); pending;) {
-                uint32_t cur_s, cur = uniform_pick(it, pending, cur_s);
-                const bool mine = it == cur;
-                pending &= ~__ballot(mine);
-                if (mine) {
-                    typedef const __attribute__((address_space(4))) DrawItem* cptr_item;
-                    cptr_item d = (cptr_item)fb.items + cur_s;
-                    if (!(d->flags & kItemSkip)) {
-                        uint32_t t = gid - d->tri_base;
-                        gptr_u32 ix = (gptr_u32)d->indices + 3ull * t;
-                        const uint32_t vb = d->vert_base, nv = d->n_verts;
-                        if (guard(t < d->n_tris, fb.counters, kGuardSetup)) {
-                            const uint32_t i0 = ix[0], i1 = ix[1], i2 = ix[2];
-                            if (guard(i0 < nv && i1 < nv && i2 < nv && vb + nv <= fc.n_verts, fb.counters, kGuardSetup)) {
-                                float4 c0 = fb.clip[vb + i0];
-                                float4 c1 = fb.clip[vb + i1];
-                                float4 c2 = fb.clip[vb + i2];
-                                setup_triangle(c0, c1, c2, gid, fc, half_w, half_h, rec, tr, emit, need_clip);
-                            }
-                        }
+            const uint32_t it = bases_in_lds ? find_item(s_bases, fc.n_items, gid) : find_item(fb.tri_bases, fc.n_items, gid);
+            typedef const __attribute__((address_space(4))) DrawItem* cptr_item;
+            auto body = [&](cptr_item d) {
+                const uint32_t vb = d->vert_base, nv = d->n_verts;
+                const uint32_t t = gid - d->tri_base;
+                if (!(d->flags & kItemSkip) && guard(t < d->n_tris && vb + nv <= fc.n_verts, fb.counters, kGuardSetup)) {
+                    gptr_u32 ix = (gptr_u32)d->indices + 3ull * t;
+                    const uint32_t i0 = ix[0], i1 = ix[1], i2 = ix[2];
+                    if (guard(i0 < nv && i1 < nv && i2 < nv, fb.counters, kGuardSetup)) {
+                        const float4 c0 = fb.clip[vb + i0];
+                        const float4 c1 = fb.clip[vb + i1];
+                        const float4 c2 = fb.clip[vb + i2];
+                        setup_triangle(c0, c1, c2, gid, fc, half_w, half_h, rec, tr, emit, need_clip);
                     }
+                }
+            };
+            // the item's fields come in through scalar loads: directly when the wave's triangles
+            // all belong to one draw item (the usual case), else one waterfall pass per item
+            const unsigned long long act = __ballot(true);
+            uint32_t lead_s;
+            const uint32_t lead = uniform_pick(it, act, lead_s);
+            if (__ballot(it != lead) == 0ull) {
+                body((cptr_item)fb.items + lead_s);
+            } else {
+                for (unsigned long long pending = act; pending;) {
+                    uint32_t cur_s, cur = uniform_pick(it, pending, cur_s);
+                    const bool mine = it == cur;
+                    pending &= ~__ballot(mine);
+                    if (mine) body((cptr_item)fb.items + cur_s);
                 }
             }
         }
@@ -420,18 +437,14 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, FrameConst fc, C
             raster_small(rec, tr.i0, tr.i1, tr.j0, tr.j1, direct_sink);
             emit = false;
         }
-        // workgroup-compacted record stream of the rest
-        unsigned long long em = __ballot(emit);
-        if (lane == 0) s_wave_cnt[iter & 1u][wave] = (uint32_t)__popcll(em);
-        __syncthreads();
-        uint32_t wave_base = 0, total = 0;
-        for (uint32_t w = 0; w < 4; ++w) {
-            uint32_t c = s_wave_cnt[iter & 1u][w];
-            if (w < wave) wave_base += c;
-            total += c;
-        }
-        const uint32_t slot = chunk_base + running + wave_base + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
-        running += total;
+        // the rest become records: the wave takes its slots from the workgroup's chunk with one LDS
+        // atomic (the waves of a workgroup do not wait for each other)
+        const unsigned long long em = __ballot(emit);
+        if (em == 0ull) continue;
+        uint32_t wave_base = 0;
+        if (lane == 0) wave_base = atomicAdd(&s_used, (uint32_t)__popcll(em));
+        wave_base = __builtin_amdgcn_readfirstlane(wave_base);
+        const uint32_t slot = chunk_base + wave_base + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
         const uint32_t pos = count_wave(emit, tr, fc, fb.tile_count, fb.tile_count + n_tiles, fb.counters);
         if (emit && guard(slot < cap.records, fb.counters, kGuardSetup)) {
             float4* dst = reinterpret_cast<float4*>(fb.records + slot);
@@ -443,7 +456,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, FrameConst fc, C
     if (lane == 0) s_valid[wave] = valid;
     __syncthreads();
     if (threadIdx.x == 0) {
-        fb.chunk_count[blockIdx.x] = running;
+        fb.chunk_count[blockIdx.x] = s_used;
         fb.chunk_count[gridDim.x + blockIdx.x] = s_valid[0] + s_valid[1] + s_valid[2] + s_valid[3];
     }
 }
