@@ -968,11 +968,8 @@ __device__ __forceinline__ void add_light_pair(const GpuLight& L, PixelPair& p) 
 
 // PPT pixels per lane: a workgroup shades 256*PPT consecutive pixels (8*PPT rows) of one tile.
 template <int PPT>
-__global__ __launch_bounds__(256) void k_shade(FrameBuffers fb, FrameConst fc) {
+__global__ __launch_bounds__(256, PPT == 2 ? 5 : 1) void k_shade(FrameBuffers fb, FrameConst fc) {
     __shared__ GpuLight s_lights[kMaxLights];
-    __shared__ uint16_t s_list[kMaxLights];
-    __shared__ float s_box[4][6];
-    __shared__ uint32_t s_cnt[4];
     __shared__ uint32_t s_bases[kLdsItems + 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const bool bases_in_lds = fc.n_items <= kLdsItems;
@@ -997,7 +994,7 @@ __global__ __launch_bounds__(256) void k_shade(FrameBuffers fb, FrameConst fc) {
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
 #pragma unroll
     for (uint32_t k = 0; k < PPT; ++k) {
-        uint32_t local = part + k * 256u + tid;
+        uint32_t local = part + wave * (64u * PPT) + k * 64u + lane;      // a wave holds 2*PPT consecutive rows
         uint32_t i = tile_x0 + (local & (kTile - 1)), j = tile_y0 + (local / kTile);
         key[k] = vis[local];
         uint32_t id = (uint32_t)(key[k] & 0xFFFFFFFFull);
@@ -1035,75 +1032,64 @@ __global__ __launch_bounds__(256) void k_shade(FrameBuffers fb, FrameConst fc) {
             }
         }
     }
-    // phase B: lights that can reach the tile.  A point light whose sphere misses the bounding box
-    // of the tile's fragments adds exactly zero to every one of them (distance > radius discards),
-    // so dropping it changes nothing; the list keeps the lights in their original order.
+    // phase B + C, per wave: the bounding box of the wave's lit fragments (2*PPT rows of the
+    // tile), then for each group of 64 lights one lane tests one light against it and the wave
+    // walks the surviving bits in ascending order.  A point light whose sphere misses the box adds
+    // exactly zero to every fragment in it (distance > radius discards), so dropping it changes
+    // nothing, and the lights keep their original order.
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         lo[c] = f32_from_ordered(wave_minmax_u32<true>(f32_ordered(lo[c])));
         hi[c] = f32_from_ordered(wave_minmax_u32<false>(f32_ordered(hi[c])));
     }
-    if (lane == 0) {
-        s_box[wave][0] = lo[0]; s_box[wave][1] = lo[1]; s_box[wave][2] = lo[2];
-        s_box[wave][3] = hi[0]; s_box[wave][4] = hi[1]; s_box[wave][5] = hi[2];
-    }
-    __syncthreads();
-    bool keep = false;
-    if (tid < fc.n_lights) {
-        float blo[3], bhi[3];
-        for (int c = 0; c < 3; ++c) {
-            blo[c] = fminf(fminf(s_box[0][c], s_box[1][c]), fminf(s_box[2][c], s_box[3][c]));
-            bhi[c] = fmaxf(fmaxf(s_box[0][c + 3], s_box[1][c + 3]), fmaxf(s_box[2][c + 3], s_box[3][c + 3]));
-        }
-        const GpuLight& L = s_lights[tid];
-        if (blo[0] <= bhi[0]) {
-            if (L.kind == RND_LIGHT_DIRECTIONAL) keep = true;
-            else {
-                float dd = 0.0f;
-                for (int c = 0; c < 3; ++c) {
-                    float e = fmaxf(fmaxf(blo[c] - L.pos[c], L.pos[c] - bhi[c]), 0.0f);
-                    dd += e * e;
-                }
-                float rr = L.radius * 1.001f + 1.0e-6f;      // conservative: never drop a light that could pass
-                keep = dd <= rr * rr;
-            }
-        }
-    }
-    unsigned long long km = __ballot(keep);
-    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(km);
-    __syncthreads();
-    uint32_t base = 0, n_list = 0;
-    for (uint32_t w = 0; w < 4; ++w) {
-        if (w < wave) base += s_cnt[w];
-        n_list += s_cnt[w];
-    }
-    if (keep) s_list[base + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = (uint16_t)tid;
-    __syncthreads();
-    // phase C: light loop
 #if RND_FAST_SHADE
+    PixelPair pp;
     if constexpr (PPT == 2) {
-        PixelPair pp;
 #define RND_PAIR(f) pp.f = (f32x2){px[0].f, px[1].f}
         RND_PAIR(fx); RND_PAIR(fy); RND_PAIR(fz); RND_PAIR(Nx); RND_PAIR(Ny); RND_PAIR(Nz); RND_PAIR(Vx); RND_PAIR(Vy);
         RND_PAIR(Vz); RND_PAIR(br); RND_PAIR(bg); RND_PAIR(bb); RND_PAIR(cr); RND_PAIR(cg); RND_PAIR(cb);
 #undef RND_PAIR
         pp.lit0 = px[0].lit; pp.lit1 = px[1].lit;
-        if (__ballot(pp.lit0 || pp.lit1))
-            for (uint32_t li = 0; li < n_list; ++li) add_light_pair(s_lights[s_list[li]], pp);
+    }
+#endif
+    if (lo[0] <= hi[0]) {
+        for (uint32_t group = 0; group < fc.n_lights; group += 64u) {
+            bool keep = false;
+            if (group + lane < fc.n_lights) {
+                const GpuLight& L = s_lights[group + lane];
+                if (L.kind == RND_LIGHT_DIRECTIONAL) keep = true;
+                else {
+                    float dd = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        float e = fmaxf(fmaxf(lo[c] - L.pos[c], L.pos[c] - hi[c]), 0.0f);
+                        dd += e * e;
+                    }
+                    float rr = L.radius * 1.001f + 1.0e-6f;      // conservative: never drop a light that could pass
+                    keep = dd <= rr * rr;
+                }
+            }
+            for (unsigned long long km = __ballot(keep); km; km &= km - 1ull) {
+                const GpuLight& L = s_lights[group + (uint32_t)(__ffsll((long long)km) - 1)];
+#if RND_FAST_SHADE
+                if constexpr (PPT == 2) { add_light_pair(L, pp); continue; }
+#endif
+#pragma unroll
+                for (uint32_t k = 0; k < PPT; ++k)
+                    if (px[k].lit) add_light(L, px[k]);
+            }
+        }
+    }
+#if RND_FAST_SHADE
+    if constexpr (PPT == 2) {
         px[0].cr = pp.cr.x; px[0].cg = pp.cg.x; px[0].cb = pp.cb.x;
         px[1].cr = pp.cr.y; px[1].cg = pp.cg.y; px[1].cb = pp.cb.y;
-    } else
-#endif
-    for (uint32_t li = 0; li < n_list; ++li) {
-        const GpuLight& L = s_lights[s_list[li]];
-#pragma unroll
-        for (uint32_t k = 0; k < PPT; ++k)
-            if (px[k].lit) add_light(L, px[k]);
     }
+#endif
     // phase D: f16 target, tone map, sRGB (show_texture.wgsl + the sRGB surface)
 #pragma unroll
     for (uint32_t k = 0; k < PPT; ++k) {
-        uint32_t local = part + k * 256u + tid;
+        uint32_t local = part + wave * (64u * PPT) + k * 64u + lane;
         uint32_t i = tile_x0 + (local & (kTile - 1)), j = tile_y0 + (local / kTile);
         bool inside = i < fc.width && j < fc.height;
         float hr = round_f16(px[k].cr), hg = round_f16(px[k].cg), hb = round_f16(px[k].cb);
