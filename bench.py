@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--lights", type=int, default=-1, help="keep only the first N lights (debug only)")
+    ap.add_argument("--as-rank", default="", help="R/W: time the share of rank R of a W-way sort-first partition on this one "
+                    "GPU, no gather (debug only: per-rank kernel times of the multi-GPU path)")
     return ap.parse_args()
 
 
@@ -116,10 +118,16 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    backend = os.environ.get("RND_BENCH_BACKEND", "nccl")      # "gloo": rehearsal of the N>1 path on fewer GPUs than ranks
+    if backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from renderer_amd import VisualServer, scenes
     builder, desc = WORKLOADS[args.workload]
@@ -132,25 +140,62 @@ def main():
     vs = VisualServer(scene.width, scene.height, device=local_rank)
     stream = torch.cuda.Stream(device=local_rank)
     vs.set_stream(stream.cuda_stream)
-    gather = None
+    gathers, comm = None, None
     if world > 1:
+        # Sort-first: every rank shades the stripes it owns into a tile-major buffer; the buffers
+        # are gathered on rank 0 (RCCL send/recv group, one xGMI link per peer) on a second stream
+        # while the next frame renders into the other buffer of the pair.
         from renderer_amd.sort_first import TileGather
         vs.set_tile_partition(rank, world)
         info = vs.tile_info()
-        gather = TileGather(rank, world, info["n_owned"], info["tile_px"], "cuda")
-        vs.set_tiles_output(gather.tiles.data_ptr(), gather.tiles.numel())
+        gathers = [TileGather(rank, world, info["n_owned"], info["tile_px"], "cuda") for _ in range(2)]
+        comm = torch.cuda.Stream(device=local_rank)
+        rendered = [torch.cuda.Event() for _ in range(2)]
+        collected = [torch.cuda.Event() for _ in range(2)]
+        detiled = [torch.cuda.Event() for _ in range(2)]     # rank 0: the gather list of this buffer has been read
+    if args.as_rank and world == 1:
+        r, w = (int(x) for x in args.as_rank.split("/"))
+        vs.set_tile_partition(r, w)
+        desc += f" (share of rank {r} of {w}, no gather)"
     driver = FrameDriver(vs, scene)
+    frame_no = [0]
 
     def step():
+        if world == 1:
+            with torch.cuda.stream(stream):
+                driver.frame()
+            return
+        b = frame_no[0] & 1
+        frame_no[0] += 1
+        g = gathers[b]
         with torch.cuda.stream(stream):
+            stream.wait_event(collected[b])           # the gather that last read this buffer is done
+            vs.set_tiles_output(g.tiles.data_ptr(), g.tiles.numel())
             driver.frame()
-            if world > 1:
-                gathered = gather.gather()
-                if rank == 0:
-                    for r in range(world):
-                        vs.api.detile(vs._ctx, r, world, C.c_void_p(gathered[r].data_ptr()))
+            rendered[b].record(stream)
+        if rank == 0:
+            detile_pending()                          # frame i-1, queued behind frame i's kernels
+        with torch.cuda.stream(comm):
+            comm.wait_event(rendered[b])
+            comm.wait_event(detiled[b])
+            gathered = g.gather()
+            collected[b].record(comm)
+        if rank == 0:
+            pending.append((b, gathered))
+
+    pending = []
+
+    def detile_pending():
+        while pending:
+            b, gathered = pending.pop(0)
+            with torch.cuda.stream(stream):
+                stream.wait_event(collected[b])
+                for r in range(world):
+                    vs.api.detile(vs._ctx, r, world, C.c_void_p(gathered[r].data_ptr()))
+                detiled[b].record(stream)
 
     def fence():
+        detile_pending()
         vs.finish()
         torch.cuda.synchronize()
         if world > 1:
@@ -178,7 +223,7 @@ def main():
     fps = args.steps / elapsed
     result = None
     if rank == 0:
-        ids = vs.read_triangle_ids() if world == 1 else None
+        ids = vs.read_triangle_ids() if world == 1 and not args.as_rank else None
         n_visible = int(np.unique(ids).size - 1) if ids is not None else stats["n_setup"]
         if ids is not None and not (ids != 0xFFFFFFFF).any():
             raise SystemExit("bench frame is empty: refusing to report a number")

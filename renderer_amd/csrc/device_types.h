@@ -15,6 +15,8 @@ constexpr float kGuardBand = 16.0f;            // guard band half-extent in NDC 
 constexpr uint32_t kMaxRenderSize = 8192;      // tile coordinates are packed in 8 bits
 constexpr uint64_t kClearKey = (uint64_t(0x3F800000u) << 32) | 0xFFFFFFFFull;   // depth 1.0, no triangle
 constexpr uint32_t kMaxLights = 256;
+constexpr uint32_t kChunkTris = 2048;          // triangles per setup work unit (one workgroup)
+constexpr uint32_t kVertexBlock = 256;         // vertices per transform workgroup
 
 // flags of a draw item
 enum : uint32_t {
@@ -23,6 +25,17 @@ enum : uint32_t {
     kItemSkip = 8u,                 // alpha test fails for every fragment (base.a < 0.5, untextured)
     kItemCastsShadows = 16u,        // RenderMeshInstance.casts_shadows (visual_server.rs:961)
 };
+
+// A run of kChunkTris consecutive triangles of a submesh, described once at registration: the
+// object-space box of its vertices and the range of vertex indices it uses.  Per frame the box is
+// projected to decide whether the chunk can touch the view volume and the screen stripes this
+// context owns (k_cull); chunks that cannot are never set up, and vertex blocks no surviving chunk
+// uses are never transformed.
+struct ChunkInfo {
+    float lo[3], hi[3];
+    uint32_t vmin, vmax;
+};
+static_assert(sizeof(ChunkInfo) == 32, "ChunkInfo is 2 x 16 bytes");
 
 // One (instance, submesh) pair of VisualServer::render's draw list (visual_server.rs:225-245).
 struct alignas(16) DrawItem {
@@ -41,7 +54,9 @@ struct alignas(16) DrawItem {
     float base_color[4];        // MaterialUniform.base_color
     uint32_t flags;
     uint32_t texture;           // index into the texture table, RND_NONE = white
-    uint32_t pad[4];
+    const ChunkInfo* chunks;    // n_chunks boxes of this submesh
+    uint32_t n_chunks;
+    uint32_t unit_base;         // index of this item's first chunk among the frame's work units
 };
 static_assert(sizeof(DrawItem) == 240, "DrawItem is copied in 16-byte pieces");
 
@@ -70,6 +85,7 @@ struct FrameConst {
     uint32_t n_items, n_lights;
     uint32_t n_tris, n_verts;
     uint32_t rank, world;
+    uint32_t n_units, pad0;        // setup work units of the frame (chunks over all draw items)
     double ndc_step_x, ndc_step_y;   // 2/width, 2/height in f64 (pixel centre -> NDC at shade time)
     float ndc_step_xf, ndc_step_yf;  // the same in f32
 };
@@ -91,13 +107,15 @@ struct FrameCounters {
     uint32_t n_entries;        // bin entries (sum of tile counts)
     uint32_t overflow;         // bit 0 records, bit 1 clip queue, bit 2 entries
     uint32_t n_valid;          // valid setup records (statistics)
-    uint32_t pad[3];
+    uint32_t n_active;         // work units that survived k_cull
+    uint32_t all_verts;        // a surviving unit uses a wide vertex range: transform every vertex block
+    uint32_t pad[1];
 };
 
 struct Capacities {
     uint32_t records;       // slots in the record stream: setup_slots + room for the clipper's records
     uint32_t clip_queue, entries;
-    uint32_t setup_slots;   // deterministic slots of k_setup: n_tris rounded up to its chunk size
+    uint32_t setup_slots;   // slots addressed by k_setup: kChunkTris per work unit
 };
 
 }  // namespace rnd

@@ -17,12 +17,15 @@ struct FrameBuffers {
     const uint32_t* vert_bases;     // n_items + 1
     const uint32_t* tri_bases;      // n_items + 1
     const GpuLight* lights;
+    const uint32_t* unit_bases;     // n_items + 1: first work unit of each item
+    uint2* active_units;            // (item, chunk) of the work units that survived k_cull
+    uint32_t* vblock_needed;        // per kVertexBlock block of the frame's vertex slots: used by a surviving unit
     // geometry stage
     float4* clip;                   // n_verts clip positions
     SetupRecord* records;
     uint2* tilewords;               // per record: .x = tx0 | ty0<<8 | (w-1)<<16 | (h-1)<<24, .y = position in its bin (single-tile records)
     uint32_t* clip_queue;           // triangle ids that need the clipper
-    uint32_t* chunk_count;          // per k_setup workgroup: [0,C) records it wrote, [C,2C) triangles that survived setup
+    uint32_t* chunk_count;          // per k_setup workgroup: [0,U) records it wrote, [U,2U) triangles that survived setup (U = n_units)
     uint32_t* tile_count;           // [0,T): single-tile records per tile; [T,2T): multi-tile records per tile
     uint32_t* tile_offset;          // per tile, exclusive scan of tile_count
     uint32_t* tile_cursor;          // per tile, fill cursor of the multi-tile records
@@ -38,10 +41,8 @@ struct FrameBuffers {
     float* hdr;                     // row-major f32 rgb (may be null; read-back only)
 };
 
-// slots k_setup addresses for n_tris triangles (its workgroups own fixed chunks of the record stream)
-uint32_t setup_slots_for(uint32_t n_tris);
-
 void launch_clear(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream);
+void launch_cull(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream);
 void launch_transform(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream);
 void launch_setup(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream);
 void launch_clip(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream);

@@ -21,7 +21,6 @@
 
 namespace rnd {
 
-uint32_t setup_slots_for(uint32_t n_tris) { return (uint32_t)(((uint64_t)n_tris + 2047u) / 2048u * 2048u); }
 
 // ------------------------------------------------------------------------------------------
 // helpers
@@ -137,12 +136,87 @@ __global__ __launch_bounds__(256) void k_clear(FrameBuffers fb, FrameConst fc) {
     }
     const uint32_t n_counts = 2u * fc.tiles_x * fc.tiles_y;
     for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n_counts; k += gridDim.x * 256u) fb.tile_count[k] = 0;
+    const uint32_t n_vblocks = (fc.n_verts + kVertexBlock - 1) / kVertexBlock;
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n_vblocks; k += gridDim.x * 256u) fb.vblock_needed[k] = 0;
     if (blockIdx.x == 0 && threadIdx.x < sizeof(FrameCounters) / 4) reinterpret_cast<uint32_t*>(fb.counters)[threadIdx.x] = 0;
+}
+
+// Work-unit culling: one thread per (draw item, chunk).  The chunk's object-space box is taken
+// through the item's vs_main transform; the unit is dropped when all eight corners lie outside one
+// plane of the view volume (with a margin far above the rounding differences to K1's per-vertex
+// results), or, on a sort-first partition, when the rows the box can cover (padded by two pixels)
+// hold no tile this context owns.  Survivors are appended to active_units and flag the vertex
+// blocks they read.
+__global__ __launch_bounds__(256) void k_cull(FrameBuffers fb, FrameConst fc) {
+    const uint32_t u = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t lane = lane_id();
+    bool active = false;
+    uint32_t it = 0, chunk = 0, vb0 = 0, vb1 = 0;
+    if (u < fc.n_units) {
+        it = find_item(fb.unit_bases, fc.n_items, u);
+        const DrawItem& d = fb.items[it];
+        chunk = u - d.unit_base;
+        const uint32_t flags = d.flags;
+        if (!(flags & kItemSkip) && guard(chunk < d.n_chunks, fb.counters, kGuardSetup)) {
+            const ChunkInfo ci = d.chunks[chunk];
+            vb0 = (d.vert_base + ci.vmin) / kVertexBlock;
+            vb1 = (d.vert_base + ci.vmax) / kVertexBlock;
+            if ((flags & kItemBillboardMask) == RND_BILLBOARD_FIXED_SIZE) {
+                active = true;      // positions do not go through projection * view
+            } else {
+                bool out_l = true, out_r = true, out_b = true, out_t = true, out_n = true, out_f = true, w_pos = true;
+                float y_lo = 3.0e38f, y_hi = -3.0e38f;
+                for (uint32_t c = 0; c < 8; ++c) {
+                    const float4 p = clip_position(d, fc, (c & 1u) ? ci.hi[0] : ci.lo[0], (c & 2u) ? ci.hi[1] : ci.lo[1],
+                                                   (c & 4u) ? ci.hi[2] : ci.lo[2]);
+                    const float e = 1.0e-3f * (fabsf(p.x) + fabsf(p.y) + fabsf(p.z) + fabsf(p.w)) + 1.0e-30f;
+                    out_l = out_l && (p.x + p.w < -e); out_r = out_r && (p.w - p.x < -e);
+                    out_b = out_b && (p.y + p.w < -e); out_t = out_t && (p.w - p.y < -e);
+                    out_n = out_n && (p.z < -e);       out_f = out_f && (p.w - p.z < -e);
+                    const bool finite = fabsf(p.x) + fabsf(p.y) + fabsf(p.z) + fabsf(p.w) < 3.0e38f;
+                    w_pos = w_pos && finite && p.w > e;
+                    const float yn = p.y / p.w;
+                    y_lo = fminf(y_lo, yn); y_hi = fmaxf(y_hi, yn);
+                }
+                active = !(out_l || out_r || out_b || out_t || out_n || out_f);
+                if (active && w_pos && fc.world > 1) {
+                    // rows the box can reach, two pixels of slack for snapping and rounding
+                    const float half_h = 0.5f * (float)fc.height;
+                    const float sy0 = (1.0f - y_hi) * half_h - 2.0f, sy1 = (1.0f - y_lo) * half_h + 2.0f;
+                    if (sy1 < 0.0f || sy0 >= (float)fc.height) active = false;
+                    else {
+                        const uint32_t ty0 = (uint32_t)fmaxf(sy0, 0.0f) / kTile;
+                        const uint32_t ty1 = min((uint32_t)fminf(sy1, (float)fc.height), fc.height - 1u) / kTile;
+                        const uint32_t g0 = ty0 / kOwnerGroup, g1 = ty1 / kOwnerGroup;
+                        bool owned = g1 - g0 + 1u >= fc.world;
+                        for (uint32_t g = g0; !owned && g <= g1; ++g) owned = (g % fc.world) == fc.rank;
+                        active = owned;
+                    }
+                }
+            }
+        }
+    }
+    const unsigned long long am = __ballot(active);
+    if (am) {
+        const int leader = __ffsll((long long)am) - 1;
+        uint32_t base = 0;
+        if (lane == (uint32_t)leader) base = atomicAdd(&fb.counters->n_active, (uint32_t)__popcll(am));
+        base = __shfl(base, leader);
+        if (active) {
+            fb.active_units[base + (uint32_t)__popcll(am & ((1ull << lane) - 1ull))] = make_uint2(it, chunk);
+            const uint32_t n_vblocks = (fc.n_verts + kVertexBlock - 1) / kVertexBlock;
+            if (vb1 - vb0 >= 64u) fb.counters->all_verts = 1u;
+            else for (uint32_t b = vb0; b <= vb1 && b < n_vblocks; ++b) fb.vblock_needed[b] = 1u;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_transform(const DrawItem* __restrict__ items,
                                                    const uint32_t* __restrict__ vert_bases, FrameConst fc,
-                                                   float4* __restrict__ clip) {
+                                                   float4* __restrict__ clip, const uint32_t* __restrict__ vblock_needed,
+                                                   const FrameCounters* __restrict__ counters) {
+    static_assert(kVertexBlock == 256, "one workgroup per vertex block");
+    if (!vblock_needed[blockIdx.x] && !counters->all_verts) return;      // no surviving work unit reads this block
     uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     if (gid >= fc.n_verts) return;
     uint32_t it = find_item(vert_bases, fc.n_items, gid);
@@ -363,59 +437,47 @@ __device__ __forceinline__ void setup_triangle(const float4& c0, const float4& c
 // (b+1)*kSetupChunk), fills them densely from the front with a ballot + LDS prefix over its
 // waves and leaves the number it used in chunk_count[b].  No global counter sits on this path (one
 // word takes ~88 atomics/us on MI355X: 10M triangles / 64 lanes on one counter cost 1.4 ms here).
-constexpr uint32_t kSetupChunk = 2048;
+constexpr uint32_t kSetupChunk = kChunkTris;
 
+// One workgroup per surviving work unit (draw item, chunk of kChunkTris triangles): the item is
+// uniform for the whole workgroup, so its fields come in through scalar loads.
 __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, FrameConst fc, Capacities cap) {
     __shared__ uint32_t s_used;         // record slots of this workgroup's chunk handed out so far
     __shared__ uint32_t s_valid[4];
-    __shared__ uint32_t s_bases[kLdsItems + 1];
+    if (blockIdx.x >= fb.counters->n_active) return;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    const bool bases_in_lds = fc.n_items <= kLdsItems;
-    if (bases_in_lds)
-        for (uint32_t k = threadIdx.x; k <= fc.n_items; k += 256u) s_bases[k] = fb.tri_bases[k];
+    const uint2 unit = fb.active_units[blockIdx.x];
+    const uint32_t item_s = __builtin_amdgcn_readfirstlane(unit.x), chunk_s = __builtin_amdgcn_readfirstlane(unit.y);
+    if (!guard(item_s < fc.n_items, fb.counters, kGuardSetup)) return;      // uniform over the workgroup
     if (threadIdx.x == 0) s_used = 0;
     __syncthreads();
+    typedef const __attribute__((address_space(4))) DrawItem* cptr_item;
+    cptr_item d = (cptr_item)fb.items + item_s;
+    const uint32_t first_t = chunk_s * kSetupChunk;                        // first triangle of the chunk within its item
+    const uint32_t item_tris = d->n_tris;
+    const uint32_t n_here = item_tris > first_t ? min(item_tris - first_t, kSetupChunk) : 0u;
+    const uint32_t vb = d->vert_base, nv = d->n_verts, tri_base = d->tri_base;
+    gptr_u32 indices = (gptr_u32)d->indices;
+    const bool tables_ok = guard(vb + nv <= fc.n_verts, fb.counters, kGuardSetup);
     const uint32_t chunk_base = blockIdx.x * kSetupChunk;
     const float half_w = 0.5f * (float)fc.width, half_h = 0.5f * (float)fc.height;
     const uint32_t n_tiles = fc.tiles_x * fc.tiles_y;
     const GlobalSink direct_sink{reinterpret_cast<unsigned long long*>(fb.vis), fc.tiles_x, fc.rank, fc.world};
     uint32_t valid = 0;
     for (uint32_t iter = 0; iter < kSetupChunk / 256u; ++iter) {
-        const uint32_t gid = chunk_base + iter * 256u + threadIdx.x;
+        const uint32_t local = iter * 256u + threadIdx.x;
+        const uint32_t gid = tri_base + first_t + local;                   // draw-order triangle id
         bool emit = false, need_clip = false;
         SetupRecord rec;
         TileRect tr{0, 0, 0, 0, 0, 0, 0, 0};
-        if (gid < fc.n_tris) {
-            const uint32_t it = bases_in_lds ? find_item(s_bases, fc.n_items, gid) : find_item(fb.tri_bases, fc.n_items, gid);
-            typedef const __attribute__((address_space(4))) DrawItem* cptr_item;
-            auto body = [&](cptr_item d) {
-                const uint32_t vb = d->vert_base, nv = d->n_verts;
-                const uint32_t t = gid - d->tri_base;
-                if (!(d->flags & kItemSkip) && guard(t < d->n_tris && vb + nv <= fc.n_verts, fb.counters, kGuardSetup)) {
-                    gptr_u32 ix = (gptr_u32)d->indices + 3ull * t;
-                    const uint32_t i0 = ix[0], i1 = ix[1], i2 = ix[2];
-                    if (guard(i0 < nv && i1 < nv && i2 < nv, fb.counters, kGuardSetup)) {
-                        const float4 c0 = fb.clip[vb + i0];
-                        const float4 c1 = fb.clip[vb + i1];
-                        const float4 c2 = fb.clip[vb + i2];
-                        setup_triangle(c0, c1, c2, gid, fc, half_w, half_h, rec, tr, emit, need_clip);
-                    }
-                }
-            };
-            // the item's fields come in through scalar loads: directly when the wave's triangles
-            // all belong to one draw item (the usual case), else one waterfall pass per item
-            const unsigned long long act = __ballot(true);
-            uint32_t lead_s;
-            const uint32_t lead = uniform_pick(it, act, lead_s);
-            if (__ballot(it != lead) == 0ull) {
-                body((cptr_item)fb.items + lead_s);
-            } else {
-                for (unsigned long long pending = act; pending;) {
-                    uint32_t cur_s, cur = uniform_pick(it, pending, cur_s);
-                    const bool mine = it == cur;
-                    pending &= ~__ballot(mine);
-                    if (mine) body((cptr_item)fb.items + cur_s);
-                }
+        if (local < n_here && tables_ok) {
+            gptr_u32 ix = indices + 3ull * (first_t + local);
+            const uint32_t i0 = ix[0], i1 = ix[1], i2 = ix[2];
+            if (guard(i0 < nv && i1 < nv && i2 < nv, fb.counters, kGuardSetup)) {
+                const float4 c0 = fb.clip[vb + i0];
+                const float4 c1 = fb.clip[vb + i1];
+                const float4 c2 = fb.clip[vb + i2];
+                setup_triangle(c0, c1, c2, gid, fc, half_w, half_h, rec, tr, emit, need_clip);
             }
         }
         // queue the triangles that need the clipper (wave-compacted, rare)
@@ -457,7 +519,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, FrameConst fc, C
     __syncthreads();
     if (threadIdx.x == 0) {
         fb.chunk_count[blockIdx.x] = s_used;
-        fb.chunk_count[gridDim.x + blockIdx.x] = s_valid[0] + s_valid[1] + s_valid[2] + s_valid[3];
+        fb.chunk_count[fc.n_units + blockIdx.x] = s_valid[0] + s_valid[1] + s_valid[2] + s_valid[3];
     }
 }
 
@@ -539,46 +601,65 @@ __global__ __launch_bounds__(256) void k_clip(FrameBuffers fb, FrameConst fc, Ca
 // --- exclusive scan of the tile counts (one workgroup) --------------------------------------
 __global__ __launch_bounds__(1024) void k_scan_tiles(FrameBuffers fb, FrameConst fc, Capacities cap) {
     __shared__ uint32_t s_wave[16];
-    __shared__ uint32_t s_carry;
+    __shared__ uint32_t s_valid[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t n_tiles = fc.tiles_x * fc.tiles_y;
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n_tiles; base += 1024u) {
-        uint32_t i = base + tid;
-        uint32_t v = i < n_tiles ? fb.tile_count[i] + fb.tile_count[n_tiles + i] : 0u;
-        uint32_t inc = v;
-        for (int o = 1; o < 64; o <<= 1) {
-            uint32_t up = __shfl_up(inc, o);
-            if (lane >= (uint32_t)o) inc += up;
-        }
-        if (lane == 63) s_wave[wave] = inc;
-        __syncthreads();
-        uint32_t wave_off = 0;
-        for (uint32_t w = 0; w < wave; ++w) wave_off += s_wave[w];
-        uint32_t carry = s_carry;
-        if (i < n_tiles) {
-            fb.tile_offset[i] = carry + wave_off + inc - v;
-            fb.tile_cursor[i] = 0;
-        }
-        __syncthreads();
-        if (tid == 1023) s_carry = carry + wave_off + inc;
-        __syncthreads();
-    }
-    // statistics: triangles that survived setup (per-chunk counts of k_setup + the clipper's)
-    const uint32_t n_chunks = cap.setup_slots / kSetupChunk;
+    // statistics: triangles that survived setup (per-unit counts of k_setup; the clipper adds its own).
+    // These loads are issued first so they overlap the scan's.
+    const uint32_t n_active = min(fb.counters->n_active, fc.n_units);
     uint32_t v = 0;
-    for (uint32_t c = tid; c < n_chunks; c += 1024u) v += fb.chunk_count[n_chunks + c];
+    for (uint32_t c = tid; c < n_active; c += 1024u) v += fb.chunk_count[fc.n_units + c];
+    // one pass: every thread owns a run of consecutive tiles (kept in registers when short), sums
+    // it, the sums are scanned over the workgroup, and the thread writes the offsets of its run
+    constexpr uint32_t kKeep = 8;
+    const uint32_t per = (n_tiles + 1023u) / 1024u;
+    const uint32_t first = tid * per, last = min(first + per, n_tiles);
+    uint32_t cnt[kKeep];
+    uint32_t sum = 0;
+    if (per <= kKeep) {
+#pragma unroll
+        for (uint32_t k = 0; k < kKeep; ++k) {
+            const uint32_t i = first + k;
+            cnt[k] = (k < per && i < n_tiles) ? fb.tile_count[i] + fb.tile_count[n_tiles + i] : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kKeep; ++k) sum += cnt[k];
+    } else {
+        for (uint32_t i = first; i < last; ++i) sum += fb.tile_count[i] + fb.tile_count[n_tiles + i];
+    }
+    uint32_t inc = sum;
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t up = __shfl_up(inc, o);
+        if (lane >= (uint32_t)o) inc += up;
+    }
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 63) s_wave[wave] = inc;
+    if (lane == 0) s_valid[wave] = v;
     __syncthreads();
-    if (lane == 0) s_wave[wave] = v;
-    __syncthreads();
-    if (tid == 0) {
+    uint32_t wave_off = 0;
+    for (uint32_t w = 0; w < wave; ++w) wave_off += s_wave[w];
+    uint32_t run = wave_off + inc - sum;
+    if (per <= kKeep) {
+#pragma unroll
+        for (uint32_t k = 0; k < kKeep; ++k) {
+            const uint32_t i = first + k;
+            if (k < per && i < n_tiles) { fb.tile_offset[i] = run; fb.tile_cursor[i] = 0; }
+            run += cnt[k];
+        }
+    } else {
+        for (uint32_t i = first; i < last; ++i) {
+            fb.tile_offset[i] = run;
+            fb.tile_cursor[i] = 0;
+            run += fb.tile_count[i] + fb.tile_count[n_tiles + i];
+        }
+    }
+    if (tid == 1023) {
+        const uint32_t n_entries = wave_off + inc;
         uint32_t total = 0;
-        for (uint32_t w = 0; w < 16; ++w) total += s_wave[w];
+        for (uint32_t w = 0; w < 16; ++w) total += s_valid[w];
         atomicAdd(&fb.counters->n_valid, total);
-        fb.counters->n_entries = s_carry;
-        if (s_carry > cap.entries) atomicOr(&fb.counters->overflow, 4u);
+        fb.counters->n_entries = n_entries;
+        if (n_entries > cap.entries) atomicOr(&fb.counters->overflow, 4u);
     }
 }
 
@@ -610,8 +691,9 @@ __device__ __forceinline__ void bin_record(const FrameBuffers& fb, const FrameCo
 constexpr uint32_t kBinClipBlocks = 64;
 
 __global__ __launch_bounds__(256) void k_bin_fill(FrameBuffers fb, FrameConst fc, Capacities cap) {
-    const uint32_t n_chunks = cap.setup_slots / kSetupChunk;
+    const uint32_t n_chunks = fc.n_units;
     if (blockIdx.x < n_chunks) {
+        if (blockIdx.x >= fb.counters->n_active) return;
         const uint32_t base = blockIdx.x * kSetupChunk;
         const uint32_t n = min(fb.chunk_count[blockIdx.x], kSetupChunk);
         for (uint32_t k = threadIdx.x; k < n; k += 256u) bin_record(fb, fc, cap, base + k);
@@ -1169,13 +1251,18 @@ void launch_clear(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stre
     hipLaunchKernelGGL(k_clear, dim3(fb.n_owned ? fb.n_owned : 1u), dim3(256), 0, stream, fb, fc);
 }
 
+void launch_cull(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream) {
+    if (fc.n_units) hipLaunchKernelGGL(k_cull, dim3(div_up(fc.n_units, 256)), dim3(256), 0, stream, fb, fc);
+}
+
 void launch_transform(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream) {
     if (!fc.n_verts) return;
-    hipLaunchKernelGGL(k_transform, dim3(div_up(fc.n_verts, 256)), dim3(256), 0, stream, fb.items, fb.vert_bases, fc, fb.clip);
+    hipLaunchKernelGGL(k_transform, dim3(div_up(fc.n_verts, 256)), dim3(256), 0, stream, fb.items, fb.vert_bases, fc, fb.clip,
+                       fb.vblock_needed, fb.counters);
 }
 void launch_setup(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {
     if (!fc.n_tris) return;
-    hipLaunchKernelGGL(k_setup, dim3(div_up(fc.n_tris, kSetupChunk)), dim3(256), 0, stream, fb, fc, cap);
+    hipLaunchKernelGGL(k_setup, dim3(fc.n_units), dim3(256), 0, stream, fb, fc, cap);
 }
 void launch_clip(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {
     if (!fc.n_tris) return;
@@ -1187,7 +1274,7 @@ void launch_scan(const FrameBuffers& fb, const FrameConst& fc, const Capacities&
 }
 void launch_bin(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {
     if (!fc.n_tris) return;
-    uint32_t blocks = cap.setup_slots / kSetupChunk + kBinClipBlocks;
+    uint32_t blocks = fc.n_units + kBinClipBlocks;
     hipLaunchKernelGGL(k_bin_fill, dim3(blocks), dim3(256), 0, stream, fb, fc, cap);
 }
 void launch_raster(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {

@@ -4,7 +4,9 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
+#include <limits>
 
 namespace rnd {
 
@@ -68,9 +70,9 @@ VisualServer::~VisualServer() {
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
     for (auto& kv : meshes_)
-        for (auto& s : kv.second.submeshes) { s.vertex_buffer.release(); s.positions.release(); s.index_buffer.release(); }
+        for (auto& s : kv.second.submeshes) { s.vertex_buffer.release(); s.positions.release(); s.index_buffer.release(); s.chunks.release(); }
     d_items_.release(); d_vert_bases_.release(); d_tri_bases_.release(); d_lights_.release(); d_clip_.release();
-    d_records_.release(); d_tilewords_.release(); d_clip_queue_.release(); d_chunk_count_.release(); d_tile_count_.release();
+    d_records_.release(); d_tilewords_.release(); d_clip_queue_.release(); d_chunk_count_.release(); d_unit_bases_.release(); d_vblock_needed_.release(); d_active_units_.release(); d_tile_count_.release();
     d_tile_offset_.release(); d_tile_cursor_.release(); d_entries_.release(); d_counters_.release();
     d_launch_order_.release(); d_vis_.release(); d_frame_.release(); d_tiles_.release(); d_packed_.release();
     d_hdr_.release();
@@ -169,7 +171,7 @@ void VisualServer::register_mesh(uint32_t mesh_id, uint32_t n_submeshes, const r
     finish();
     auto old = meshes_.find(mesh_id);
     if (old != meshes_.end()) {
-        for (auto& s : old->second.submeshes) { s.vertex_buffer.release(); s.positions.release(); s.index_buffer.release(); }
+        for (auto& s : old->second.submeshes) { s.vertex_buffer.release(); s.positions.release(); s.index_buffer.release(); s.chunks.release(); }
         meshes_.erase(old);
     }
     RenderMesh mesh;
@@ -185,6 +187,30 @@ void VisualServer::register_mesh(uint32_t mesh_id, uint32_t n_submeshes, const r
         // one-time AoS -> SoA transpose of the positions for the vertex-transform kernel
         launch_split_positions(s.vertex_buffer.ptr, d.n_vertices, s.positions.ptr, s.positions.ptr + d.n_vertices,
                                s.positions.ptr + 2 * (size_t)d.n_vertices, stream_);
+        // per-chunk object-space boxes and vertex ranges for the per-frame work-unit culling
+        const uint32_t n_tris = d.n_indices / 3;
+        s.n_chunks = (n_tris + kChunkTris - 1) / kChunkTris;
+        std::vector<ChunkInfo> infos(s.n_chunks);
+        const float inf = std::numeric_limits<float>::infinity();
+        for (uint32_t c = 0; c < s.n_chunks; ++c) {
+            ChunkInfo ci;
+            for (int a = 0; a < 3; ++a) { ci.lo[a] = inf; ci.hi[a] = -inf; }
+            ci.vmin = 0xFFFFFFFFu; ci.vmax = 0;
+            const size_t i_end = std::min<size_t>((size_t)(c + 1) * kChunkTris * 3, d.n_indices);
+            for (size_t i = (size_t)c * kChunkTris * 3; i < i_end; ++i) {
+                const uint32_t v = d.indices[i];
+                ci.vmin = std::min(ci.vmin, v); ci.vmax = std::max(ci.vmax, v);
+                const float* p = d.vertices[v].position;
+                for (int a = 0; a < 3; ++a) {
+                    // a non-finite coordinate opens the box completely: such a chunk is never culled
+                    if (!std::isfinite(p[a])) { ci.lo[a] = -inf; ci.hi[a] = inf; }
+                    else { ci.lo[a] = std::min(ci.lo[a], p[a]); ci.hi[a] = std::max(ci.hi[a], p[a]); }
+                }
+            }
+            infos[c] = ci;
+        }
+        s.chunks.ensure(std::max<size_t>(s.n_chunks, 1));
+        if (s.n_chunks) HIP_CHECK(hipMemcpy(s.chunks.ptr, infos.data(), infos.size() * sizeof(ChunkInfo), hipMemcpyHostToDevice));
         mesh.submeshes.push_back(s);
     }
     HIP_CHECK(hipStreamSynchronize(stream_));   // the caller may free its arrays on return
@@ -246,7 +272,7 @@ void VisualServer::reset_scene() {
     finish();
     for (auto it = meshes_.begin(); it != meshes_.end();) {
         if (it->first == kQuadMeshId) { ++it; continue; }
-        for (auto& s : it->second.submeshes) { s.vertex_buffer.release(); s.positions.release(); s.index_buffer.release(); }
+        for (auto& s : it->second.submeshes) { s.vertex_buffer.release(); s.positions.release(); s.index_buffer.release(); s.chunks.release(); }
         it = meshes_.erase(it);
     }
     materials_.clear(); lights_.clear(); mesh_instances_.clear(); sprite_materials_.clear();
@@ -254,9 +280,10 @@ void VisualServer::reset_scene() {
 
 // ---- frame -------------------------------------------------------------------------------------
 void VisualServer::build_frame(std::vector<DrawItem>& items, std::vector<uint32_t>& vert_bases,
-                               std::vector<uint32_t>& tri_bases, std::vector<GpuLight>& lights) {
+                               std::vector<uint32_t>& tri_bases, std::vector<uint32_t>& unit_bases,
+                               std::vector<GpuLight>& lights) {
     const Mat4 pv = projection_ * view_;
-    uint64_t vert_base = 0, tri_base = 0;
+    uint64_t vert_base = 0, tri_base = 0, unit_base = 0;
     // for mesh_instance { for submesh } — visual_server.rs:227-245
     for (const RenderMeshInstance& inst : mesh_instances_) {
         const RenderMesh& mesh = meshes_.at(inst.mesh);
@@ -292,15 +319,19 @@ void VisualServer::build_frame(std::vector<DrawItem>& items, std::vector<uint32_
             d.flags = mat.billboard_mode | (mat.unlit ? kItemUnlit : 0u) | (inst.casts_shadows ? kItemCastsShadows : 0u);
             if (mat.base_color[3] * 1.0f < 0.5f) d.flags |= kItemSkip;   // alpha test, untextured (render_mesh.wgsl:91)
             d.texture = mat.texture;
+            d.chunks = s.chunks.ptr; d.n_chunks = s.n_chunks; d.unit_base = (uint32_t)unit_base;
             vert_bases.push_back(d.vert_base);
             tri_bases.push_back(d.tri_base);
-            vert_base += d.n_verts; tri_base += d.n_tris;
-            if (vert_base >= 0xFFFFFFFFull || tri_base >= 0xFFFFFFFFull) throw Error(RND_ERR_INVALID, "frame exceeds 2^32 vertices or triangles");
+            unit_bases.push_back(d.unit_base);
+            vert_base += d.n_verts; tri_base += d.n_tris; unit_base += d.n_chunks;
+            if (vert_base >= 0xFFFFFFFFull || tri_base >= 0xFFFFFFFFull || unit_base * kChunkTris >= 0xFFFFFFF0ull) throw Error(RND_ERR_INVALID, "frame exceeds 2^32 vertices or triangles");
             items.push_back(d);
         }
     }
     vert_bases.push_back((uint32_t)vert_base);
     tri_bases.push_back((uint32_t)tri_base);
+    unit_bases.push_back((uint32_t)unit_base);
+    fc_.n_units = (uint32_t)unit_base;
     for (const RenderLight& l : lights_) {
         GpuLight g{};
         g.pos[0] = l.transform.col[3].x; g.pos[1] = l.transform.col[3].y; g.pos[2] = l.transform.col[3].z;
@@ -331,14 +362,14 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 void VisualServer::enqueue_frame(bool want_hdr) {
     use_device();
     std::vector<DrawItem> items;
-    std::vector<uint32_t> vert_bases, tri_bases;
+    std::vector<uint32_t> vert_bases, tri_bases, unit_bases;
     std::vector<GpuLight> lights;
-    build_frame(items, vert_bases, tri_bases, lights);
+    build_frame(items, vert_bases, tri_bases, unit_bases, lights);
     const FrameConst& fc = fc_;
     const size_t n_tiles = (size_t)tiles_x_ * tiles_y_;
 
     // capacities
-    cap_.setup_slots = setup_slots_for(fc.n_tris);
+    cap_.setup_slots = fc.n_units * kChunkTris;
     clip_records_ = std::max<uint32_t>(clip_records_, fc.n_tris / 8 + 4096);
     cap_.records = (uint32_t)std::min<uint64_t>((uint64_t)cap_.setup_slots + clip_records_, 0xFFFFFFF0ull);
     if (cap_.clip_queue < std::max<uint32_t>(fc.n_tris / 8, 65536)) cap_.clip_queue = std::max<uint32_t>(fc.n_tris / 8, 65536);
@@ -350,7 +381,10 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     d_clip_.ensure(std::max<size_t>(fc.n_verts, 1));
     d_records_.ensure(cap_.records); d_tilewords_.ensure(2 * (size_t)cap_.records);
     d_clip_queue_.ensure(cap_.clip_queue);
-    d_chunk_count_.ensure(std::max<size_t>(2 * (size_t)(cap_.setup_slots / 2048u), 2));
+    d_chunk_count_.ensure(std::max<size_t>(2 * (size_t)fc.n_units, 2));
+    d_active_units_.ensure(std::max<size_t>(2 * (size_t)fc.n_units, 2));
+    d_unit_bases_.ensure(unit_bases.size());
+    d_vblock_needed_.ensure((size_t)fc.n_verts / kVertexBlock + 2);
     d_entries_.ensure(cap_.entries);
     if (world_ > 1) d_tiles_.ensure(std::max<size_t>((size_t)n_owned_ * kTilePixels * 4, 4));
     if (want_packed_) d_packed_.ensure((size_t)width_ * height_);
@@ -360,7 +394,8 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     const size_t off_items = 0;
     const size_t off_vb = align_up(off_items + items.size() * sizeof(DrawItem), 256);
     const size_t off_tb = align_up(off_vb + vert_bases.size() * 4, 256);
-    const size_t off_li = align_up(off_tb + tri_bases.size() * 4, 256);
+    const size_t off_ub = align_up(off_tb + tri_bases.size() * 4, 256);
+    const size_t off_li = align_up(off_ub + unit_bases.size() * 4, 256);
     const size_t total = align_up(off_li + lights.size() * sizeof(GpuLight), 256) + 256;
     Staging& st = staging_[staging_next_];
     staging_next_ = (staging_next_ + 1) % 3;
@@ -375,10 +410,12 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     if (!items.empty()) std::memcpy(h + off_items, items.data(), items.size() * sizeof(DrawItem));
     std::memcpy(h + off_vb, vert_bases.data(), vert_bases.size() * 4);
     std::memcpy(h + off_tb, tri_bases.data(), tri_bases.size() * 4);
+    std::memcpy(h + off_ub, unit_bases.data(), unit_bases.size() * 4);
     if (!lights.empty()) std::memcpy(h + off_li, lights.data(), lights.size() * sizeof(GpuLight));
     if (!items.empty()) HIP_CHECK(hipMemcpyAsync(d_items_.ptr, h + off_items, items.size() * sizeof(DrawItem), hipMemcpyHostToDevice, stream_));
     HIP_CHECK(hipMemcpyAsync(d_vert_bases_.ptr, h + off_vb, vert_bases.size() * 4, hipMemcpyHostToDevice, stream_));
     HIP_CHECK(hipMemcpyAsync(d_tri_bases_.ptr, h + off_tb, tri_bases.size() * 4, hipMemcpyHostToDevice, stream_));
+    HIP_CHECK(hipMemcpyAsync(d_unit_bases_.ptr, h + off_ub, unit_bases.size() * 4, hipMemcpyHostToDevice, stream_));
     if (!lights.empty()) HIP_CHECK(hipMemcpyAsync(d_lights_.ptr, h + off_li, lights.size() * sizeof(GpuLight), hipMemcpyHostToDevice, stream_));
     HIP_CHECK(hipEventRecord(st.done, stream_));
     st.in_flight = true;
@@ -387,6 +424,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     fb.items = d_items_.ptr; fb.vert_bases = d_vert_bases_.ptr; fb.tri_bases = d_tri_bases_.ptr; fb.lights = d_lights_.ptr;
     fb.clip = d_clip_.ptr; fb.records = d_records_.ptr; fb.tilewords = reinterpret_cast<uint2*>(d_tilewords_.ptr); fb.clip_queue = d_clip_queue_.ptr;
     fb.chunk_count = d_chunk_count_.ptr;
+    fb.unit_bases = d_unit_bases_.ptr; fb.active_units = reinterpret_cast<uint2*>(d_active_units_.ptr); fb.vblock_needed = d_vblock_needed_.ptr;
     fb.tile_count = d_tile_count_.ptr; fb.tile_offset = d_tile_offset_.ptr; fb.tile_cursor = d_tile_cursor_.ptr;
     fb.entries = d_entries_.ptr; fb.counters = d_counters_.ptr;
     fb.launch_order = d_launch_order_.ptr; fb.n_owned = n_owned_;
@@ -402,7 +440,8 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     event_next_ = (event_next_ + 1) % kEventSets;
     hipEvent_t* ev_ = es.ev;
     HIP_CHECK(hipEventRecord(ev_[0], stream_));
-    launch_clear(fb, fc, stream_);      // visibility words, tile counts, frame counters
+    launch_clear(fb, fc, stream_);      // visibility words, tile counts, vertex-block flags, frame counters
+    launch_cull(fb, fc, stream_);       // work units that can reach the view volume and this context's stripes
     launch_transform(fb, fc, stream_);
     HIP_CHECK(hipEventRecord(ev_[1], stream_));
     launch_setup(fb, fc, cap_, stream_);
@@ -495,7 +534,8 @@ rnd_timings VisualServer::mean_timings(uint32_t& n_frames, bool reset) {
 }
 
 void VisualServer::set_tiles_output(void* dev_ptr, uint64_t bytes) {
-    finish();
+    // only read when the next frame is enqueued: frames already in flight keep the buffer they were
+    // launched with, so a caller may alternate two buffers without draining the stream
     if (dev_ptr && bytes < (uint64_t)n_owned_ * kTilePixels * 4) throw Error(RND_ERR_INVALID, "tile output buffer too small");
     ext_tiles_ = static_cast<uint8_t*>(dev_ptr);
     ext_tiles_bytes_ = bytes;

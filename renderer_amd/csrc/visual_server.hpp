@@ -53,6 +53,8 @@ struct RenderSubmesh {           // visual_server.rs:948-953
     DeviceBuffer<rnd_vertex> vertex_buffer;
     DeviceBuffer<float> positions;       // px | py | pz, n_verts each
     DeviceBuffer<uint32_t> index_buffer;
+    DeviceBuffer<ChunkInfo> chunks;      // one per kChunkTris triangles
+    uint32_t n_chunks = 0;
     uint32_t index_count = 0, vertex_count = 0;
     uint32_t material = RND_NONE;
 };
@@ -127,6 +129,7 @@ private:
     void rebuild_tiles();
     std::vector<uint32_t> owned_tiles(uint32_t rank, uint32_t world) const;
     void build_frame(std::vector<DrawItem>& items, std::vector<uint32_t>& vert_bases, std::vector<uint32_t>& tri_bases,
+                     std::vector<uint32_t>& unit_bases,
                      std::vector<GpuLight>& lights);
     void enqueue_frame(bool want_hdr);
     void need_frame() const;
@@ -175,7 +178,7 @@ private:
     DeviceBuffer<GpuLight> d_lights_;
     DeviceBuffer<float4> d_clip_;
     DeviceBuffer<SetupRecord> d_records_;
-    DeviceBuffer<uint32_t> d_tilewords_, d_clip_queue_, d_chunk_count_, d_tile_count_, d_tile_offset_, d_tile_cursor_, d_entries_;
+    DeviceBuffer<uint32_t> d_tilewords_, d_clip_queue_, d_chunk_count_, d_unit_bases_, d_vblock_needed_, d_active_units_, d_tile_count_, d_tile_offset_, d_tile_cursor_, d_entries_;
     DeviceBuffer<FrameCounters> d_counters_;
     DeviceBuffer<TileRef> d_launch_order_;
     DeviceBuffer<uint64_t> d_vis_;

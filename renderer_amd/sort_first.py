@@ -40,7 +40,7 @@ class TileGather:
 
     def __init__(self, rank, world, n_owned, tile_px, device):
         self.rank, self.world, self.tile_bytes = rank, world, tile_px * tile_px * 4
-        t = torch.tensor([n_owned], dtype=torch.int64, device=device)
+        t = torch.tensor([n_owned], dtype=torch.int64, device="cpu" if dist.get_backend() == "gloo" else device)
         counts = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(counts, t)
         self.counts = [int(c.item()) for c in counts]
@@ -49,6 +49,15 @@ class TileGather:
 
     def gather(self):
         """Collect every rank's `tiles` buffer on rank 0 (a send/recv group, no ring)."""
+        if dist.get_backend() == "gloo" and self.tiles.is_cuda:
+            # rehearsal on a box with fewer GPUs than ranks: gloo gathers host tensors only
+            host = self.tiles.cpu()
+            parts = [torch.empty_like(host) for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(host, parts, dst=0)
+            if self.rank == 0:
+                for dst, src in zip(self.gathered, parts):
+                    dst.copy_(src)
+            return self.gathered
         dist.gather(self.tiles, self.gathered, dst=0)
         return self.gathered
 
