@@ -15,7 +15,7 @@ constexpr float kGuardBand = 16.0f;            // guard band half-extent in NDC 
 constexpr uint32_t kMaxRenderSize = 8192;      // tile coordinates are packed in 8 bits
 constexpr uint64_t kClearKey = (uint64_t(0x3F800000u) << 32) | 0xFFFFFFFFull;   // depth 1.0, no triangle
 constexpr uint32_t kMaxLights = 256;
-constexpr uint32_t kChunkTris = 2048;          // triangles per setup work unit (one workgroup)
+constexpr uint32_t kChunkTris = 1024;          // triangles per setup work unit (one workgroup)
 constexpr uint32_t kVertexBlock = 256;         // vertices per transform workgroup
 
 // flags of a draw item

@@ -19,6 +19,10 @@
 
 #include "kernels.h"
 
+#ifndef RND_EARLY_Z
+#define RND_EARLY_Z 0
+#endif
+
 namespace rnd {
 
 
@@ -322,6 +326,11 @@ struct GlobalSink {
         if (z < 1.0f && owns_tile(tx, ty, rank, world)) {
             unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | id;
             const size_t at = (size_t)(ty * tiles_x + tx) * kTilePixels + (((uint32_t)j % kTile) * kTile + ((uint32_t)i % kTile));
+#if RND_EARLY_Z
+            // early test with a plain (possibly stale) load: the word only ever decreases, so a stale
+            // value can cause a redundant atomic, never a skipped one
+            if (!(key < vis[at])) return;
+#endif
             __hip_atomic_fetch_min(&vis[at], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -608,7 +617,16 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(FrameBuffers fb, FrameConst
     // These loads are issued first so they overlap the scan's.
     const uint32_t n_active = min(fb.counters->n_active, fc.n_units);
     uint32_t v = 0;
-    for (uint32_t c = tid; c < n_active; c += 1024u) v += fb.chunk_count[fc.n_units + c];
+    for (uint32_t c0 = 0; c0 < n_active; c0 += 8u * 1024u) {
+        uint32_t part[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {          // eight independent loads in flight, not a chain of round trips
+            const uint32_t c = c0 + k * 1024u + tid;
+            part[k] = c < n_active ? fb.chunk_count[fc.n_units + c] : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) v += part[k];
+    }
     // one pass: every thread owns a run of consecutive tiles (kept in registers when short), sums
     // it, the sums are scanned over the workgroup, and the thread writes the offsets of its run
     constexpr uint32_t kKeep = 8;
