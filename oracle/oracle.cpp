@@ -31,7 +31,10 @@
 //                      additive Equal-depth pass per (mesh, light) into an f16 target.
 #include <algorithm>
 #include <atomic>
+#include <cfloat>
 #include <chrono>
+#include <cmath>
+#include <cstring>
 #include <cstdio>
 #include <map>
 #include <string>
@@ -56,7 +59,11 @@ struct Submesh { std::vector<Vertex> verts; std::vector<uint32_t> idx; uint32_t 
 struct Mesh { std::vector<Submesh> subs; };
 struct Material { float base[4]; uint32_t billboard, unlit, texture; };
 struct Texture { uint32_t w, h, mips; std::vector<uint8_t> data; };
-struct Light { uint64_t id; M4 transform; float color[4]; uint32_t kind; float radius; };
+struct Light {
+    uint64_t id; M4 transform; float color[4]; uint32_t kind; float radius;
+    M4 cascades[4];                 // world -> light clip of the four shadow cascades, as of set_light
+    std::vector<std::vector<float>> shadow;   // per frame: 4 x SHADOW_DIM^2 depths (directional lights)
+};
 struct Instance { uint64_t id; M4 transform; uint32_t mesh, mat_override; bool casts_shadows; };
 
 struct DrawItem {
@@ -257,6 +264,7 @@ struct Ctx {
     M4 proj = perspective_lh(1.3f, 1.667f, 0.05f, 100.0f);   // Camera::default(), visual_server.rs:64
     M4 view = identity();
     M4 cam = identity();
+    M4 inv_pv = identity();            // RenderScene::inv_projection_view (Default = identity), visual_server.rs:898
     float ambient[4] = {0.3f, 0.5f, 0.9f, 0.04f};             // visual_server.rs:67
 
     // frame outputs
@@ -391,6 +399,81 @@ static V3 blinn_phong(V3 base, V3 n, V3 to_view, V3 light_dir, V3 light_color, f
     return base * (diffuse + spec);
 }
 
+// compute_shadow_cascade_projviews (visual_server.rs:771-863): slices of the camera frustum
+// (ratios 0-0.05-0.1-0.3-1, :88), a light view looking along light_dir from each slice's
+// centroid, an orthographic box around the slice with its z range widened tenfold.
+static void shadow_cascade_projviews(const M4& inv_pv, V3 light_dir, M4 out[4]) {
+    auto frustum_point = [&](float x, float y, float z) {
+        V4 fp = mul(inv_pv, V4{x, y, z, 1.0f});
+        return V4{fp.x / fp.w, fp.y / fp.w, fp.z / fp.w, fp.w / fp.w};
+    };
+    const V4 n[4] = {frustum_point(-1, 1, 0), frustum_point(1, 1, 0), frustum_point(-1, -1, 0), frustum_point(1, -1, 0)};
+    const V4 f[4] = {frustum_point(-1, 1, 1), frustum_point(1, 1, 1), frustum_point(-1, -1, 1), frustum_point(1, -1, 1)};
+    V4 edge[4];
+    for (int k = 0; k < 4; ++k) edge[k] = V4{f[k].x - n[k].x, f[k].y - n[k].y, f[k].z - n[k].z, f[k].w - n[k].w};
+    const float ratios[4][2] = {{0.0f, 0.05f}, {0.05f, 0.1f}, {0.1f, 0.3f}, {0.3f, 1.0f}};
+    for (int cascade = 0; cascade < 4; ++cascade) {
+        V4 corner[8];
+        for (int k = 0; k < 4; ++k) {
+            const float rn = ratios[cascade][0], rf = ratios[cascade][1];
+            corner[k] = V4{n[k].x + edge[k].x * rn, n[k].y + edge[k].y * rn, n[k].z + edge[k].z * rn, n[k].w + edge[k].w * rn};
+            corner[4 + k] = V4{n[k].x + edge[k].x * rf, n[k].y + edge[k].y * rf, n[k].z + edge[k].z * rf, n[k].w + edge[k].w * rf};
+        }
+        V4 sum = corner[0];
+        for (int k = 1; k < 8; ++k) sum = V4{sum.x + corner[k].x, sum.y + corner[k].y, sum.z + corner[k].z, sum.w + corner[k].w};
+        V3 center{sum.x / 8.0f, sum.y / 8.0f, sum.z / 8.0f};
+        M4 view = look_to_lh(center, light_dir, V3{0, 1, 0});
+        float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};   // f32::MAX / f32::MIN
+        for (int k = 0; k < 8; ++k) {
+            V4 p = mul(view, corner[k]);
+            mn[0] = std::fmin(mn[0], p.x); mx[0] = std::fmax(mx[0], p.x);
+            mn[1] = std::fmin(mn[1], p.y); mx[1] = std::fmax(mx[1], p.y);
+            mn[2] = std::fmin(mn[2], p.z); mx[2] = std::fmax(mx[2], p.z);
+        }
+        const float z_mult = 10.0f;
+        if (mn[2] < 0.0f) mn[2] *= z_mult; else mn[2] /= z_mult;
+        if (mx[2] < 0.0f) mx[2] /= z_mult; else mx[2] *= z_mult;
+        out[cascade] = mul(orthographic_lh(mn[0], mx[0], mn[1], mx[1], mn[2], mx[2]), view);
+    }
+}
+
+// compute_light_occlusion (render_mesh.wgsl:184-252).  The shader selects layer 3 beyond view
+// depth 30 but LightUniform holds three matrices (:118, visual_server.rs:409-413); naga's
+// "Restrict" index policy clamps the index, so layer 3 is looked up through cascade 2's matrix.
+// Nearest sampler, ClampToBorder with OpaqueWhite (backend.rs:441-453): depth 1.0 outside.
+static float light_occlusion(const Ctx& c, const Light& l, V3 frag_pos, V3 normal, V3 light_dir) {
+    if (dot(normal, light_dir) > 0.0f) return 0.0f;
+    int layer; float bias_mod;
+    const float view_depth = mul_point(c.view, frag_pos).z;
+    if (view_depth <= 0.05f * 100.0f) { layer = 0; bias_mod = 0.03f; }
+    else if (view_depth <= 0.1f * 100.0f) { layer = 1; bias_mod = 0.05f; }
+    else if (view_depth <= 0.3f * 100.0f) { layer = 2; bias_mod = 0.1f; }
+    else { layer = 3; bias_mod = 0.2f; }
+    V3 depth_offset = neg(light_dir) * 0.3f;
+    V3 normal_offset = normal * 0.8f;
+    V3 biased = frag_pos + (depth_offset + normal_offset) * bias_mod;
+    V4 ls = mul(l.cascades[layer < 2 ? layer : 2], V4{biased.x, biased.y, biased.z, 1.0f});
+    float nx = ls.x / ls.w, ny = ls.y / ls.w, nz = ls.z / ls.w;
+    float u = (nx + 1.0f) * 0.5f, v = 1.0f - (ny + 1.0f) * 0.5f;
+    float frag_depth = clampf(nz, 0.0f, 1.0f);
+    const float texel = 1.0f / (float)SHADOW_DIM;
+    const std::vector<float>& map = l.shadow[layer];
+    float occlusion = 0.0f, samples = 0.0f;
+    for (int x = -1; x <= 1; ++x)
+        for (int y = -1; y <= 1; ++y) {
+            samples += 1.0f;
+            float su = u + (float)x * texel, sv = v + (float)y * texel;
+            float occluder = 1.0f;                                  // border colour
+            if (su >= 0.0f && su < 1.0f && sv >= 0.0f && sv < 1.0f) {
+                uint32_t ix = std::min((uint32_t)std::floor(su * (float)SHADOW_DIM), SHADOW_DIM - 1);
+                uint32_t iy = std::min((uint32_t)std::floor(sv * (float)SHADOW_DIM), SHADOW_DIM - 1);
+                occluder = map[(size_t)iy * SHADOW_DIM + ix];
+            }
+            if (frag_depth > occluder) occlusion += 1.0f;
+        }
+    return occlusion / samples;
+}
+
 // contribution of one light to one fragment (fs_main_blinn_phong, render_mesh.wgsl:134-181);
 // returns false when the fragment is discarded for this light
 static bool light_contribution(const Ctx& c, const Light& l, const Frag& f, V3 base, V3& out) {
@@ -399,7 +482,7 @@ static bool light_contribution(const Ctx& c, const Light& l, const Frag& f, V3 b
     V3 to_view = normalize(cam_pos - f.pos);
     if (l.kind == RND_LIGHT_DIRECTIONAL) {
         V3 dir{l.transform.c[8], l.transform.c[9], l.transform.c[10]};
-        float occlusion = 0.0f;   // shadow cascades: SURVEY.md §8f row N1 (not built yet)
+        float occlusion = light_occlusion(c, l, f.pos, n, dir);
         out = blinn_phong(base, n, to_view, dir, V3{l.color[0], l.color[1], l.color[2]},
                           l.color[3] * (1.0f - occlusion));
         return true;
@@ -491,6 +574,44 @@ static int render(Ctx& c) {
         });
         nv += s.verts.size();
         nt += s.idx.size() / 3;
+    }
+
+    // Shadow maps of the directional lights: depth-only passes over every item that casts shadows
+    // (pipeline3d.rs:268-313; no fragment stage, so no alpha test; render_shadow_map.wgsl:25-33 uses
+    // the model matrix only, billboard modes do not apply), cull Back, depth Less against 1.0.
+    // The reference also fills maps for point lights, which nothing reads.
+    for (Light& l : c.lights) {
+        l.shadow.clear();
+        if (l.kind != RND_LIGHT_DIRECTIONAL) continue;
+        l.shadow.resize(4);
+        for (int cascade = 0; cascade < 4; ++cascade) {
+            const size_t n_px = (size_t)SHADOW_DIM * SHADOW_DIM;
+            std::vector<std::atomic<uint32_t>> depth(n_px);
+            for (size_t k = 0; k < n_px; ++k) depth[k].store(0x3F800000u, std::memory_order_relaxed);
+            for (const DrawItem& it : items) {
+                if (!it.casts_shadows) continue;
+                const Submesh& s = *it.sub;
+                std::vector<V4> lc(s.verts.size());
+                parallel_for(c.threads, s.verts.size(), [&](size_t lo, size_t hi) {
+                    for (size_t k = lo; k < hi; ++k) lc[k] = mul(l.cascades[cascade], mul_point(it.model, s.verts[k].pos));
+                });
+                parallel_for(c.threads, s.idx.size() / 3, [&](size_t lo, size_t hi) {
+                    for (size_t t = lo; t < hi; ++t)
+                        raster_triangle(lc[s.idx[3 * t]], lc[s.idx[3 * t + 1]], lc[s.idx[3 * t + 2]], SHADOW_DIM, SHADOW_DIM,
+                                        [&](uint32_t i, uint32_t j, float z) {
+                                            if (!(z < 1.0f)) return;
+                                            std::atomic<uint32_t>& a = depth[(size_t)j * SHADOW_DIM + i];
+                                            uint32_t v = fbits(z), cur = a.load(std::memory_order_relaxed);
+                                            while (v < cur && !a.compare_exchange_weak(cur, v, std::memory_order_relaxed)) {}
+                                        });
+                });
+            }
+            l.shadow[cascade].resize(n_px);
+            for (size_t k = 0; k < n_px; ++k) {
+                uint32_t bits = depth[k].load(std::memory_order_relaxed);
+                std::memcpy(&l.shadow[cascade][k], &bits, 4);
+            }
+        }
     }
 
     // K2+K3: visibility (nearest fragment; ties -> lowest triangle id = first in draw order).
@@ -711,12 +832,15 @@ int orc_set_camera(rnd_ctx* ctx, const float t[16], float vfov, float aspect, fl
     c->cam = load_m4(t);
     c->proj = orc::perspective_lh(vfov, aspect, zn, zf);
     c->view = orc::affine_inverse(c->cam);
+    c->inv_pv = orc::inverse(orc::mul(c->proj, c->view));        // visual_server.rs:210
     return RND_OK;
 }
 int orc_set_light(rnd_ctx* ctx, uint64_t id, const float t[16], const float color[4], uint32_t kind, float radius) {
     Ctx* c = CTX(ctx);
     if (!t || !color || kind > 1) { c->err = "bad light"; return RND_ERR_INVALID; }
-    orc::Light l{id, load_m4(t), {color[0], color[1], color[2], color[3]}, kind, kind == RND_LIGHT_POINT ? radius : 0.0f};
+    orc::Light l{id, load_m4(t), {color[0], color[1], color[2], color[3]}, kind, kind == RND_LIGHT_POINT ? radius : 0.0f, {}, {}};
+    // cascades follow the camera as of this call (create_light / update_light, visual_server.rs:380-381, :445-446)
+    orc::shadow_cascade_projviews(c->inv_pv, orc::V3{l.transform.c[8], l.transform.c[9], l.transform.c[10]}, l.cascades);
     for (auto& e : c->lights) if (e.id == id) { e = l; return RND_OK; }
     c->lights.push_back(l);
     return RND_OK;
@@ -797,6 +921,14 @@ int orc_get_matrices(rnd_ctx* ctx, float proj[16], float view[16], float projvie
     std::memcpy(proj, c->proj.c, 64); std::memcpy(view, c->view.c, 64);
     orc::M4 pv = orc::mul(c->proj, c->view); std::memcpy(projview, pv.c, 64);
     return RND_OK;
+}
+/* the four world -> light-clip matrices of a light's shadow cascades, as of its last set_light */
+int orc_get_light_cascades(rnd_ctx* ctx, uint64_t id, float out[64]) {
+    Ctx* c = CTX(ctx);
+    for (const auto& l : c->lights)
+        if (l.id == id) { for (int k = 0; k < 4; ++k) std::memcpy(out + 16 * k, l.cascades[k].c, 64); return RND_OK; }
+    c->err = "no such light";
+    return RND_ERR_UNKNOWN_ID;
 }
 /* tile-major RGBA8 of the owned tiles, as the product's rnd_tiles_device_ptr buffer (host copy) */
 int orc_read_tiles(rnd_ctx* ctx, uint8_t* dst) {

@@ -17,6 +17,8 @@ constexpr uint64_t kClearKey = (uint64_t(0x3F800000u) << 32) | 0xFFFFFFFFull;   
 constexpr uint32_t kMaxLights = 256;
 constexpr uint32_t kChunkTris = 1024;          // triangles per setup work unit (one workgroup)
 constexpr uint32_t kVertexBlock = 256;         // vertices per transform workgroup
+constexpr uint32_t kShadowSize = 2048;         // shadow map edge (visual_server.rs:366-367)
+constexpr uint32_t kShadowCascades = 4;        // settings.shadow_cascades (visual_server.rs:88)
 
 // flags of a draw item
 enum : uint32_t {
@@ -70,6 +72,15 @@ struct GpuLight {
     int32_t shadow_index;   // index of this light's cascade set, -1 = none
     float inv_radius;       // 1 / radius (point lights)
     uint32_t pad[2];
+};
+
+// Shadow cascades of one directional light as the shading kernel reads them: the three matrices the
+// reference uploads (LightUniform::cascades_world_to_light, visual_server.rs:409-413) and the four
+// depth layers, each the tile-major visibility words of a kShadowSize^2 depth-only pass (depth bits
+// in the high half).
+struct ShadowSet {
+    float world_to_light[3][16];
+    const uint64_t* layers[kShadowCascades];
 };
 
 // Per-frame constants passed by value to the kernels.

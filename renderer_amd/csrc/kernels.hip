@@ -983,12 +983,63 @@ __device__ __forceinline__ void prepare_pixel(const DrawItem& d, const FrameCons
     }
 }
 
+// compute_light_occlusion (render_mesh.wgsl:184-252): cascade by view depth, biased position
+// through the cascade's matrix, 3x3 nearest taps (ClampToBorder, OpaqueWhite: depth 1 outside the
+// map, backend.rs:441-453).  The shader can select layer 3 although the uniform holds three
+// matrices (:118, :203): with naga's index clamping that layer is read through matrix 2.
+__device__ __forceinline__ float light_occlusion(const ShadowSet* __restrict__ sets, int32_t set, const FrameConst& fc,
+                                                 float fx, float fy, float fz, float nx, float ny, float nz,
+                                                 float lx, float ly, float lz) {
+    if (set < 0) return 0.0f;
+    if (dot3(nx, ny, nz, lx, ly, lz) > 0.0f) return 0.0f;
+    const ShadowSet& S = sets[set];
+    const float view_depth = ((fc.view[2] * fx + fc.view[6] * fy) + fc.view[10] * fz) + fc.view[14];
+    uint32_t layer; float bias_mod;
+    if (view_depth <= 0.05f * 100.0f) { layer = 0; bias_mod = 0.03f; }
+    else if (view_depth <= 0.1f * 100.0f) { layer = 1; bias_mod = 0.05f; }
+    else if (view_depth <= 0.3f * 100.0f) { layer = 2; bias_mod = 0.1f; }
+    else { layer = 3; bias_mod = 0.2f; }
+    const float ox = ((-lx) * 0.3f + nx * 0.8f) * bias_mod, oy = ((-ly) * 0.3f + ny * 0.8f) * bias_mod,
+                oz = ((-lz) * 0.3f + nz * 0.8f) * bias_mod;
+    const float bx = fx + ox, by = fy + oy, bz = fz + oz;
+    const float* m = S.world_to_light[layer < 2u ? layer : 2u];
+    const float cx = ((m[0] * bx + m[4] * by) + m[8] * bz) + m[12] * 1.0f;
+    const float cy = ((m[1] * bx + m[5] * by) + m[9] * bz) + m[13] * 1.0f;
+    const float cz = ((m[2] * bx + m[6] * by) + m[10] * bz) + m[14] * 1.0f;
+    const float cw = ((m[3] * bx + m[7] * by) + m[11] * bz) + m[15] * 1.0f;
+    const float qx = cx / cw, qy = cy / cw, qz = cz / cw;
+    const float u = (qx + 1.0f) * 0.5f, v = 1.0f - (qy + 1.0f) * 0.5f;
+    const float frag_depth = fminf(fmaxf(qz, 0.0f), 1.0f);
+    const float texel = 1.0f / (float)kShadowSize;
+    const uint64_t* __restrict__ map = S.layers[layer];
+    constexpr uint32_t kTilesX = kShadowSize / kTile;
+    float occlusion = 0.0f;
+#pragma unroll
+    for (int x = -1; x <= 1; ++x)
+#pragma unroll
+        for (int y = -1; y <= 1; ++y) {
+            const float su = u + (float)x * texel, sv = v + (float)y * texel;
+            float occluder = 1.0f;
+            if (su >= 0.0f && su < 1.0f && sv >= 0.0f && sv < 1.0f) {
+                const uint32_t ix = min((uint32_t)floorf(su * (float)kShadowSize), kShadowSize - 1u);
+                const uint32_t iy = min((uint32_t)floorf(sv * (float)kShadowSize), kShadowSize - 1u);
+                const size_t at = (size_t)((iy / kTile) * kTilesX + ix / kTile) * kTilePixels + ((iy % kTile) * kTile + ix % kTile);
+                occluder = __uint_as_float((uint32_t)(map[at] >> 32));
+            }
+            if (frag_depth > occluder) occlusion += 1.0f;
+        }
+    return occlusion / 9.0f;
+}
+
 // fs_main_blinn_phong for one light and one fragment (render_mesh.wgsl:134-181, :256-281)
-__device__ __forceinline__ void add_light(const GpuLight& L, PixelInputs& p) {
+template <bool kShadows>
+__device__ __forceinline__ void add_light(const GpuLight& L, PixelInputs& p, const ShadowSet* __restrict__ sets,
+                                          const FrameConst& fc) {
     float dx, dy, dz, intensity;
     if (L.kind == RND_LIGHT_DIRECTIONAL) {
         dx = L.dir[0]; dy = L.dir[1]; dz = L.dir[2];
         float occlusion = 0.0f;
+        if constexpr (kShadows) occlusion = light_occlusion(sets, L.shadow_index, fc, p.fx, p.fy, p.fz, p.Nx, p.Ny, p.Nz, dx, dy, dz);
         intensity = L.color[3] * (1.0f - occlusion);
     } else {
         float ox = p.fx - L.pos[0], oy = p.fy - L.pos[1], oz = p.fz - L.pos[2];
@@ -1034,12 +1085,24 @@ __device__ __forceinline__ f32x2 splat2(float v) { return (f32x2){v, v}; }
 __device__ __forceinline__ f32x2 rsq2(f32x2 v) { return (f32x2){__builtin_amdgcn_rsqf(v.x), __builtin_amdgcn_rsqf(v.y)}; }
 __device__ __forceinline__ f32x2 max0(f32x2 v) { return (f32x2){fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f)}; }
 
-__device__ __forceinline__ void add_light_pair(const GpuLight& L, PixelPair& p) {
+__device__ __forceinline__ float shadow_term(const ShadowSet* __restrict__ sets, const GpuLight& L, const FrameConst& fc,
+                                             float fx, float fy, float fz, float nx, float ny, float nz) {
+    return light_occlusion(sets, L.shadow_index, fc, fx, fy, fz, nx, ny, nz, L.dir[0], L.dir[1], L.dir[2]);
+}
+
+template <bool kShadows>
+__device__ __forceinline__ void add_light_pair(const GpuLight& L, PixelPair& p, const ShadowSet* __restrict__ sets,
+                                               const FrameConst& fc) {
 #pragma clang fp contract(fast)
     f32x2 dx, dy, dz, inten;
     if (L.kind == RND_LIGHT_DIRECTIONAL) {
         dx = splat2(L.dir[0]); dy = splat2(L.dir[1]); dz = splat2(L.dir[2]);
-        inten = (f32x2){p.lit0 ? L.color[3] : 0.0f, p.lit1 ? L.color[3] : 0.0f};
+        float i0 = p.lit0 ? L.color[3] : 0.0f, i1 = p.lit1 ? L.color[3] : 0.0f;
+        if constexpr (kShadows) {
+            if (p.lit0) i0 = L.color[3] * (1.0f - shadow_term(sets, L, fc, p.fx.x, p.fy.x, p.fz.x, p.Nx.x, p.Ny.x, p.Nz.x));
+            if (p.lit1) i1 = L.color[3] * (1.0f - shadow_term(sets, L, fc, p.fx.y, p.fy.y, p.fz.y, p.Nx.y, p.Ny.y, p.Nz.y));
+        }
+        inten = (f32x2){i0, i1};
     } else {
         f32x2 ox = p.fx - splat2(L.pos[0]), oy = p.fy - splat2(L.pos[1]), oz = p.fz - splat2(L.pos[2]);
         f32x2 d2 = ox * ox + oy * oy + oz * oz;
@@ -1067,8 +1130,10 @@ __device__ __forceinline__ void add_light_pair(const GpuLight& L, PixelPair& p) 
 #endif
 
 // PPT pixels per lane: a workgroup shades 256*PPT consecutive pixels (8*PPT rows) of one tile.
-template <int PPT>
-__global__ __launch_bounds__(256, PPT == 2 ? 5 : 1) void k_shade(FrameBuffers fb, FrameConst fc) {
+// kShadows: the frame has directional lights with cascade sets (the lookup costs registers, so
+// frames without them run the variant compiled without it).
+template <int PPT, bool kShadows>
+__global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(FrameBuffers fb, FrameConst fc) {
     __shared__ GpuLight s_lights[kMaxLights];
     __shared__ uint32_t s_bases[kLdsItems + 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -1172,11 +1237,11 @@ __global__ __launch_bounds__(256, PPT == 2 ? 5 : 1) void k_shade(FrameBuffers fb
             for (unsigned long long km = __ballot(keep); km; km &= km - 1ull) {
                 const GpuLight& L = s_lights[group + (uint32_t)(__ffsll((long long)km) - 1)];
 #if RND_FAST_SHADE
-                if constexpr (PPT == 2) { add_light_pair(L, pp); continue; }
+                if constexpr (PPT == 2) { add_light_pair<kShadows>(L, pp, fb.shadow_sets, fc); continue; }
 #endif
 #pragma unroll
                 for (uint32_t k = 0; k < PPT; ++k)
-                    if (px[k].lit) add_light(L, px[k]);
+                    if (px[k].lit) add_light<kShadows>(L, px[k], fb.shadow_sets, fc);
             }
         }
     }
@@ -1302,9 +1367,17 @@ void launch_raster(const FrameBuffers& fb, const FrameConst& fc, const Capacitie
 void launch_shade(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream) {
     if (!fb.n_owned) return;
     static const int ppt = [] { const char* e = getenv("RND_SHADE_PPT"); int v = e ? atoi(e) : 2; return (v == 1 || v == 2 || v == 4) ? v : 1; }();
-    if (ppt == 4) hipLaunchKernelGGL(k_shade<4>, dim3(fb.n_owned), dim3(256), 0, stream, fb, fc);
-    else if (ppt == 2) hipLaunchKernelGGL(k_shade<2>, dim3(fb.n_owned * 2), dim3(256), 0, stream, fb, fc);
-    else hipLaunchKernelGGL(k_shade<1>, dim3(fb.n_owned * 4), dim3(256), 0, stream, fb, fc);
+    const bool sh = fb.shadow_sets != nullptr;
+    if (ppt == 4) {
+        if (sh) hipLaunchKernelGGL((k_shade<4, true>), dim3(fb.n_owned), dim3(256), 0, stream, fb, fc);
+        else hipLaunchKernelGGL((k_shade<4, false>), dim3(fb.n_owned), dim3(256), 0, stream, fb, fc);
+    } else if (ppt == 2) {
+        if (sh) hipLaunchKernelGGL((k_shade<2, true>), dim3(fb.n_owned * 2), dim3(256), 0, stream, fb, fc);
+        else hipLaunchKernelGGL((k_shade<2, false>), dim3(fb.n_owned * 2), dim3(256), 0, stream, fb, fc);
+    } else {
+        if (sh) hipLaunchKernelGGL((k_shade<1, true>), dim3(fb.n_owned * 4), dim3(256), 0, stream, fb, fc);
+        else hipLaunchKernelGGL((k_shade<1, false>), dim3(fb.n_owned * 4), dim3(256), 0, stream, fb, fc);
+    }
 }
 void launch_extract(const uint64_t* vis, const TileRef* order, uint32_t n_owned, const FrameConst& fc, float* depth,
                     uint32_t* ids, uint8_t* coverage, hipStream_t stream) {

@@ -145,6 +145,48 @@ inline Mat4 inverse(const Mat4& mm) {
     return Mat4::from_cols_array(r);
 }
 
+// compute_shadow_cascade_projviews (visual_server.rs:771-863): world -> light clip of the four
+// shadow cascades of a directional light, from the inverse projection*view current at the call.
+// Frustum slices at the ratios of settings.shadow_cascades (visual_server.rs:88).
+inline void shadow_cascade_projviews(const Mat4& inv_projection_view, Vec3 light_dir, Mat4 out[4]) {
+    auto unproject = [&](float x, float y, float z) {
+        const Vec4 p = transform(inv_projection_view, Vec4{x, y, z, 1.0f});
+        return Vec4{p.x / p.w, p.y / p.w, p.z / p.w, p.w / p.w};
+    };
+    const float sx[4] = {-1.0f, 1.0f, -1.0f, 1.0f}, sy[4] = {1.0f, 1.0f, -1.0f, -1.0f};   // tl, tr, bl, br
+    Vec4 near_c[4], edge[4];
+    for (int k = 0; k < 4; ++k) {
+        near_c[k] = unproject(sx[k], sy[k], 0.0f);
+        const Vec4 far_c = unproject(sx[k], sy[k], 1.0f);
+        edge[k] = Vec4{far_c.x - near_c[k].x, far_c.y - near_c[k].y, far_c.z - near_c[k].z, far_c.w - near_c[k].w};
+    }
+    static const float kSlices[4][2] = {{0.0f, 0.05f}, {0.05f, 0.1f}, {0.1f, 0.3f}, {0.3f, 1.0f}};
+    for (int c = 0; c < 4; ++c) {
+        Vec4 corners[8];
+        for (int half = 0; half < 2; ++half)
+            for (int k = 0; k < 4; ++k) {
+                const float r = kSlices[c][half];
+                corners[half * 4 + k] = Vec4{near_c[k].x + edge[k].x * r, near_c[k].y + edge[k].y * r,
+                                             near_c[k].z + edge[k].z * r, near_c[k].w + edge[k].w * r};
+            }
+        Vec4 acc = corners[0];
+        for (int k = 1; k < 8; ++k) acc = Vec4{acc.x + corners[k].x, acc.y + corners[k].y, acc.z + corners[k].z, acc.w + corners[k].w};
+        const Mat4 view = look_to_lh(Vec3{acc.x / 8.0f, acc.y / 8.0f, acc.z / 8.0f}, light_dir, Vec3{0.0f, 1.0f, 0.0f});
+        float lo[3] = {3.40282347e+38f, 3.40282347e+38f, 3.40282347e+38f};
+        float hi[3] = {-3.40282347e+38f, -3.40282347e+38f, -3.40282347e+38f};
+        for (const Vec4& corner : corners) {
+            const Vec4 p = transform(view, corner);
+            lo[0] = std::fmin(lo[0], p.x); hi[0] = std::fmax(hi[0], p.x);
+            lo[1] = std::fmin(lo[1], p.y); hi[1] = std::fmax(hi[1], p.y);
+            lo[2] = std::fmin(lo[2], p.z); hi[2] = std::fmax(hi[2], p.z);
+        }
+        // include casters outside the slice: widen the z range tenfold
+        lo[2] = lo[2] < 0.0f ? lo[2] * 10.0f : lo[2] / 10.0f;
+        hi[2] = hi[2] < 0.0f ? hi[2] / 10.0f : hi[2] * 10.0f;
+        out[c] = orthographic_lh(lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]) * view;
+    }
+}
+
 // IEEE binary16 round-to-nearest-even, widened back to f32 (the Rgba16Float clear colour)
 inline float round_to_f16(float f) {
     uint32_t u;

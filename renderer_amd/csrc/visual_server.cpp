@@ -56,7 +56,7 @@ VisualServer::VisualServer(uint32_t width, uint32_t height, int device) : device
     projection_ = perspective_lh(1.3f, 1.667f, 0.05f, 100.0f);
     view_ = Mat4::identity();
     camera_transform_ = Mat4::identity();
-    inv_projection_view_ = inverse(projection_ * view_);
+    inv_projection_view_ = Mat4::identity();     // RenderScene::default() (visual_server.rs:896-898): identity until set_camera
     rebuild_tiles();
     // initialize_default_resources — visual_server.rs:865-873 (unit quad; default material is implicit)
     static const rnd_vertex quad[4] = {{{-0.5f, 0.5f, 0.0f}, {0, 0, -1}, {0, 0}}, {{0.5f, 0.5f, 0.0f}, {0, 0, -1}, {1, 0}},
@@ -74,6 +74,8 @@ VisualServer::~VisualServer() {
     d_items_.release(); d_vert_bases_.release(); d_tri_bases_.release(); d_lights_.release(); d_clip_.release();
     d_records_.release(); d_tilewords_.release(); d_clip_queue_.release(); d_chunk_count_.release(); d_unit_bases_.release(); d_vblock_needed_.release(); d_active_units_.release(); d_tile_count_.release();
     d_tile_offset_.release(); d_tile_cursor_.release(); d_entries_.release(); d_counters_.release();
+    d_shadow_items_.release(); d_shadow_sets_.release(); d_shadow_order_.release();
+    for (auto& b : shadow_layers_) b.release();
     d_launch_order_.release(); d_vis_.release(); d_frame_.release(); d_tiles_.release(); d_packed_.release();
     d_hdr_.release();
     for (auto& kv : detile_lists_) kv.second.list.release();
@@ -238,10 +240,14 @@ void VisualServer::set_light(UniqueNodeId id, const Mat4& transform, const Light
     if (light.kind > 1) throw Error(RND_ERR_INVALID, "light kind must be 0 (directional) or 1 (point)");
     Light l = light;
     if (l.kind != RND_LIGHT_POINT) l.radius = 0.0f;   // Light::radius().unwrap_or_default()
+    RenderLight rl{id, transform, l, {}};
+    // create_light / update_light recompute the cascades from the camera current at the call
+    // (visual_server.rs:380-381, :445-446); set_camera does not (:221 FIXME)
+    shadow_cascade_projviews(inv_projection_view_, transform.axis(2), rl.cascades);
     for (auto& e : lights_)
-        if (e.id == id) { e.transform = transform; e.light = l; return; }
+        if (e.id == id) { e = rl; return; }
     if (lights_.size() >= kMaxLights) throw Error(RND_ERR_INVALID, "too many lights (max 256)");
-    lights_.push_back(RenderLight{id, transform, l});
+    lights_.push_back(rl);
 }
 
 void VisualServer::set_mesh_instance(UniqueNodeId id, const Mat4& transform, uint32_t mesh_id, uint32_t material_override,
@@ -281,7 +287,7 @@ void VisualServer::reset_scene() {
 // ---- frame -------------------------------------------------------------------------------------
 void VisualServer::build_frame(std::vector<DrawItem>& items, std::vector<uint32_t>& vert_bases,
                                std::vector<uint32_t>& tri_bases, std::vector<uint32_t>& unit_bases,
-                               std::vector<GpuLight>& lights) {
+                               std::vector<GpuLight>& lights, std::vector<DrawItem>& shadow_items) {
     const Mat4 pv = projection_ * view_;
     uint64_t vert_base = 0, tri_base = 0, unit_base = 0;
     // for mesh_instance { for submesh } — visual_server.rs:227-245
@@ -326,6 +332,13 @@ void VisualServer::build_frame(std::vector<DrawItem>& items, std::vector<uint32_
             vert_base += d.n_verts; tri_base += d.n_tris; unit_base += d.n_chunks;
             if (vert_base >= 0xFFFFFFFFull || tri_base >= 0xFFFFFFFFull || unit_base * kChunkTris >= 0xFFFFFFF0ull) throw Error(RND_ERR_INVALID, "frame exceeds 2^32 vertices or triangles");
             items.push_back(d);
+            // the same geometry as the shadow passes draw it (render_shadow_map.wgsl:25-33: model matrix
+            // only, no billboard modes; pipeline3d.rs:268-313: no fragment stage, so no alpha test;
+            // instances with casts_shadows = false are skipped)
+            DrawItem sd = d;
+            inst.transform.to_cols_array(sd.world);
+            sd.flags = inst.casts_shadows ? 0u : kItemSkip;
+            shadow_items.push_back(sd);
         }
     }
     vert_bases.push_back((uint32_t)vert_base);
@@ -364,7 +377,46 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     std::vector<DrawItem> items;
     std::vector<uint32_t> vert_bases, tri_bases, unit_bases;
     std::vector<GpuLight> lights;
-    build_frame(items, vert_bases, tri_bases, unit_bases, lights);
+    std::vector<DrawItem> shadow_items;
+    build_frame(items, vert_bases, tri_bases, unit_bases, lights, shadow_items);
+    // every directional light owns a cascade set (the reference also fills maps for point lights,
+    // which its shader never reads: visual_server.rs:358-436, render_mesh.wgsl:150-152)
+    std::vector<uint32_t> shadowed;
+    for (uint32_t i = 0; i < lights.size(); ++i)
+        if (lights[i].kind == RND_LIGHT_DIRECTIONAL) { lights[i].shadow_index = (int32_t)shadowed.size(); shadowed.push_back(i); }
+    const uint32_t n_sets = fc_.n_tris ? (uint32_t)shadowed.size() : 0u;
+    if (!n_sets) for (auto& l : lights) l.shadow_index = -1;
+    const uint32_t n_passes = n_sets * kShadowCascades;
+    constexpr uint32_t kShadowTiles = (kShadowSize / kTile) * (kShadowSize / kTile);
+    std::vector<ShadowSet> sets(n_sets);
+    if (n_sets) {
+        if (shadow_layers_.size() < n_sets) shadow_layers_.resize(n_sets);
+        for (uint32_t k = 0; k < n_sets; ++k) {
+            shadow_layers_[k].ensure((size_t)kShadowCascades * kShadowTiles * kTilePixels);
+            const RenderLight& rl = lights_[shadowed[k]];
+            for (int c = 0; c < 3; ++c) rl.cascades[c].to_cols_array(sets[k].world_to_light[c]);
+            for (uint32_t c = 0; c < kShadowCascades; ++c) sets[k].layers[c] = shadow_layers_[k].ptr + (size_t)c * kShadowTiles * kTilePixels;
+        }
+        d_shadow_items_.ensure(std::max<size_t>(shadow_items.size(), 1));
+        d_shadow_sets_.ensure(n_sets);
+        if (!d_shadow_order_.ptr) {
+            std::vector<TileRef> order(kShadowTiles);
+            for (uint32_t t = 0; t < kShadowTiles; ++t) order[t] = TileRef{t, t};
+            d_shadow_order_.ensure(kShadowTiles);
+            HIP_CHECK(hipMemcpy(d_shadow_order_.ptr, order.data(), kShadowTiles * sizeof(TileRef), hipMemcpyHostToDevice));
+        }
+        const size_t need = std::max<size_t>((size_t)tiles_x_ * tiles_y_, kShadowTiles);
+        d_tile_count_.ensure(2 * need); d_tile_offset_.ensure(need); d_tile_cursor_.ensure(need);
+    }
+    n_counter_sets_ = 1 + n_passes;
+    d_counters_.ensure(n_counter_sets_);
+    if (h_counter_sets_ < n_counter_sets_) {
+        if (frame_pending_) HIP_CHECK(hipStreamSynchronize(stream_));
+        if (h_counters_) HIP_CHECK(hipHostFree(h_counters_));
+        h_counters_ = nullptr;
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_counters_), n_counter_sets_ * sizeof(FrameCounters), hipHostMallocDefault));
+        h_counter_sets_ = n_counter_sets_;
+    }
     const FrameConst& fc = fc_;
     const size_t n_tiles = (size_t)tiles_x_ * tiles_y_;
 
@@ -396,7 +448,9 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     const size_t off_tb = align_up(off_vb + vert_bases.size() * 4, 256);
     const size_t off_ub = align_up(off_tb + tri_bases.size() * 4, 256);
     const size_t off_li = align_up(off_ub + unit_bases.size() * 4, 256);
-    const size_t total = align_up(off_li + lights.size() * sizeof(GpuLight), 256) + 256;
+    const size_t off_si = align_up(off_li + lights.size() * sizeof(GpuLight), 256);
+    const size_t off_ss = align_up(off_si + (n_sets ? shadow_items.size() * sizeof(DrawItem) : 0), 256);
+    const size_t total = align_up(off_ss + n_sets * sizeof(ShadowSet), 256) + 256;
     Staging& st = staging_[staging_next_];
     staging_next_ = (staging_next_ + 1) % 3;
     if (st.in_flight) { HIP_CHECK(hipEventSynchronize(st.done)); st.in_flight = false; }
@@ -417,11 +471,18 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     HIP_CHECK(hipMemcpyAsync(d_tri_bases_.ptr, h + off_tb, tri_bases.size() * 4, hipMemcpyHostToDevice, stream_));
     HIP_CHECK(hipMemcpyAsync(d_unit_bases_.ptr, h + off_ub, unit_bases.size() * 4, hipMemcpyHostToDevice, stream_));
     if (!lights.empty()) HIP_CHECK(hipMemcpyAsync(d_lights_.ptr, h + off_li, lights.size() * sizeof(GpuLight), hipMemcpyHostToDevice, stream_));
+    if (n_sets) {
+        std::memcpy(h + off_si, shadow_items.data(), shadow_items.size() * sizeof(DrawItem));
+        std::memcpy(h + off_ss, sets.data(), n_sets * sizeof(ShadowSet));
+        if (!shadow_items.empty()) HIP_CHECK(hipMemcpyAsync(d_shadow_items_.ptr, h + off_si, shadow_items.size() * sizeof(DrawItem), hipMemcpyHostToDevice, stream_));
+        HIP_CHECK(hipMemcpyAsync(d_shadow_sets_.ptr, h + off_ss, n_sets * sizeof(ShadowSet), hipMemcpyHostToDevice, stream_));
+    }
     HIP_CHECK(hipEventRecord(st.done, stream_));
     st.in_flight = true;
 
     FrameBuffers fb{};
     fb.items = d_items_.ptr; fb.vert_bases = d_vert_bases_.ptr; fb.tri_bases = d_tri_bases_.ptr; fb.lights = d_lights_.ptr;
+    fb.shadow_sets = n_sets ? d_shadow_sets_.ptr : nullptr;      // null selects the shading kernel without the lookup
     fb.clip = d_clip_.ptr; fb.records = d_records_.ptr; fb.tilewords = reinterpret_cast<uint2*>(d_tilewords_.ptr); fb.clip_queue = d_clip_queue_.ptr;
     fb.chunk_count = d_chunk_count_.ptr;
     fb.unit_bases = d_unit_bases_.ptr; fb.active_units = reinterpret_cast<uint2*>(d_active_units_.ptr); fb.vblock_needed = d_vblock_needed_.ptr;
@@ -439,6 +500,30 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     last_set_ = (int)event_next_;
     event_next_ = (event_next_ + 1) % kEventSets;
     hipEvent_t* ev_ = es.ev;
+    // shadow cascades: depth-only passes of the same pipeline (cull, transform, setup, bins, raster)
+    // into kShadowSize^2 visibility buffers, one per (directional light, cascade)
+    HIP_CHECK(hipEventRecord(ev_[7], stream_));
+    for (uint32_t k = 0; k < n_sets; ++k)
+        for (uint32_t c = 0; c < kShadowCascades; ++c) {
+            FrameBuffers sfb = fb;
+            sfb.items = d_shadow_items_.ptr; sfb.lights = nullptr; sfb.shadow_sets = nullptr;
+            sfb.counters = d_counters_.ptr + 1 + k * kShadowCascades + c;
+            sfb.launch_order = d_shadow_order_.ptr; sfb.n_owned = kShadowTiles;
+            sfb.vis = shadow_layers_[k].ptr + (size_t)c * kShadowTiles * kTilePixels;
+            sfb.frame_rgba8 = nullptr; sfb.tiles_rgba8 = nullptr; sfb.packed = nullptr; sfb.hdr = nullptr;
+            FrameConst sfc = fc;
+            lights_[shadowed[k]].cascades[c].to_cols_array(sfc.pv);
+            sfc.width = sfc.height = kShadowSize; sfc.tiles_x = sfc.tiles_y = kShadowSize / kTile;
+            sfc.rank = 0; sfc.world = 1; sfc.n_lights = 0;
+            launch_clear(sfb, sfc, stream_);
+            launch_cull(sfb, sfc, stream_);
+            launch_transform(sfb, sfc, stream_);
+            launch_setup(sfb, sfc, cap_, stream_);
+            launch_clip(sfb, sfc, cap_, stream_);
+            launch_scan(sfb, sfc, cap_, stream_);
+            launch_bin(sfb, sfc, cap_, stream_);
+            launch_raster(sfb, sfc, cap_, stream_);
+        }
     HIP_CHECK(hipEventRecord(ev_[0], stream_));
     launch_clear(fb, fc, stream_);      // visibility words, tile counts, vertex-block flags, frame counters
     launch_cull(fb, fc, stream_);       // work units that can reach the view volume and this context's stripes
@@ -456,7 +541,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     launch_shade(fb, fc, stream_);
     HIP_CHECK(hipEventRecord(ev_[6], stream_));
     es.pending = true;
-    HIP_CHECK(hipMemcpyAsync(h_counters_, d_counters_.ptr, sizeof(FrameCounters), hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipMemcpyAsync(h_counters_, d_counters_.ptr, n_counter_sets_ * sizeof(FrameCounters), hipMemcpyDeviceToHost, stream_));
     HIP_CHECK(hipGetLastError());
     frame_pending_ = true;
     stats_ = rnd_frame_stats{};
@@ -474,7 +559,13 @@ void VisualServer::finish() {
     for (int attempt = 0; attempt < 8; ++attempt) {
         HIP_CHECK(hipStreamSynchronize(stream_));
         frame_pending_ = false;
-        const FrameCounters c = *h_counters_;
+        FrameCounters c = h_counters_[0];
+        for (uint32_t k = 1; k < n_counter_sets_; ++k) {       // shadow passes share the streams: take the largest demand
+            const FrameCounters& o = h_counters_[k];
+            c.overflow |= o.overflow;
+            c.n_records = std::max(c.n_records, o.n_records); c.n_clip = std::max(c.n_clip, o.n_clip);
+            c.n_entries = std::max(c.n_entries, o.n_entries);
+        }
         if (c.overflow & ~7u) {
             char msg[96];
             std::snprintf(msg, sizeof msg, "internal consistency check failed in a kernel (flags 0x%x)", c.overflow);
@@ -505,13 +596,15 @@ void VisualServer::finish() {
 
 // Reads one completed frame's events into timings_ and the running sums.
 void VisualServer::harvest(EventSet& es) {
-    HIP_CHECK(hipEventSynchronize(es.ev[kEventsPerSet - 1]));
+    HIP_CHECK(hipEventSynchronize(es.ev[6]));
     float ms[6] = {};
     for (int k = 0; k < 6; ++k) HIP_CHECK(hipEventElapsedTime(&ms[k], es.ev[k], es.ev[k + 1]));
     timings_ = rnd_timings{};
     timings_.transform_ms = ms[0]; timings_.setup_ms = ms[1]; timings_.scan_ms = ms[2]; timings_.bin_ms = ms[3];
     timings_.raster_ms = ms[4]; timings_.shade_ms = ms[5];
-    HIP_CHECK(hipEventElapsedTime(&timings_.frame_ms, es.ev[0], es.ev[6]));
+    HIP_CHECK(hipEventElapsedTime(&timings_.shadow_ms, es.ev[7], es.ev[0]));
+    HIP_CHECK(hipEventElapsedTime(&timings_.frame_ms, es.ev[7], es.ev[6]));
+    timing_sum_[7] += timings_.shadow_ms;
     for (int k = 0; k < 6; ++k) timing_sum_[k] += ms[k];
     timing_sum_[6] += timings_.frame_ms;
     timing_frames_ += 1;
@@ -527,7 +620,7 @@ rnd_timings VisualServer::mean_timings(uint32_t& n_frames, bool reset) {
         m.transform_ms = (float)(timing_sum_[0] * inv); m.setup_ms = (float)(timing_sum_[1] * inv);
         m.scan_ms = (float)(timing_sum_[2] * inv); m.bin_ms = (float)(timing_sum_[3] * inv);
         m.raster_ms = (float)(timing_sum_[4] * inv); m.shade_ms = (float)(timing_sum_[5] * inv);
-        m.frame_ms = (float)(timing_sum_[6] * inv);
+        m.frame_ms = (float)(timing_sum_[6] * inv); m.shadow_ms = (float)(timing_sum_[7] * inv);
     }
     if (reset) { for (double& v : timing_sum_) v = 0.0; timing_frames_ = 0; }
     return m;

@@ -59,7 +59,10 @@ struct RenderSubmesh {           // visual_server.rs:948-953
     uint32_t material = RND_NONE;
 };
 struct RenderMesh { std::vector<RenderSubmesh> submeshes; };
-struct RenderLight { UniqueNodeId id; Mat4 transform; Light light; };
+struct RenderLight {
+    UniqueNodeId id; Mat4 transform; Light light;
+    Mat4 cascades[4];     // RenderShadowCascade::projview x4 (visual_server.rs:380-405), as of the last set_light
+};
 struct RenderMeshInstance {      // visual_server.rs:955-962
     UniqueNodeId id;
     Mat4 transform;
@@ -130,7 +133,7 @@ private:
     std::vector<uint32_t> owned_tiles(uint32_t rank, uint32_t world) const;
     void build_frame(std::vector<DrawItem>& items, std::vector<uint32_t>& vert_bases, std::vector<uint32_t>& tri_bases,
                      std::vector<uint32_t>& unit_bases,
-                     std::vector<GpuLight>& lights);
+                     std::vector<GpuLight>& lights, std::vector<DrawItem>& shadow_items);
     void enqueue_frame(bool want_hdr);
     void need_frame() const;
 
@@ -145,7 +148,7 @@ private:
     hipStream_t stream_ = nullptr;
     bool own_stream_ = true;
     // ring of per-frame event sets, so kernel timings can be harvested without a per-frame sync
-    static constexpr int kEventSets = 16, kEventsPerSet = 7;
+    static constexpr int kEventSets = 16, kEventsPerSet = 8;      // [7] = before the shadow passes
     struct EventSet {
         hipEvent_t ev[kEventsPerSet] = {};
         bool pending = false;
@@ -179,7 +182,13 @@ private:
     DeviceBuffer<float4> d_clip_;
     DeviceBuffer<SetupRecord> d_records_;
     DeviceBuffer<uint32_t> d_tilewords_, d_clip_queue_, d_chunk_count_, d_unit_bases_, d_vblock_needed_, d_active_units_, d_tile_count_, d_tile_offset_, d_tile_cursor_, d_entries_;
-    DeviceBuffer<FrameCounters> d_counters_;
+    DeviceBuffer<FrameCounters> d_counters_;        // [0] main pass, then one per shadow pass
+    uint32_t n_counter_sets_ = 1, h_counter_sets_ = 0;
+    // shadow cascades of the directional lights
+    DeviceBuffer<DrawItem> d_shadow_items_;
+    DeviceBuffer<ShadowSet> d_shadow_sets_;
+    DeviceBuffer<TileRef> d_shadow_order_;
+    std::vector<DeviceBuffer<uint64_t>> shadow_layers_;   // per shadowed light: kShadowCascades visibility buffers
     DeviceBuffer<TileRef> d_launch_order_;
     DeviceBuffer<uint64_t> d_vis_;
     DeviceBuffer<uint8_t> d_frame_, d_tiles_;

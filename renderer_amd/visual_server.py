@@ -153,13 +153,19 @@ class VisualServer:
         self._check(self.api.set_light(self._ctx, int(id), _fp(t), _fp(col), light.kind_id(),
                                        float(light.radius() or 0.0)))
 
-    def set_mesh_instance(self, id, transform, mesh_handle: Handle, asset_server=None):
-        """visual_server.rs:481-506"""
+    def set_mesh_instance(self, id, transform, mesh_handle: Handle, asset_server=None, material_override=None,
+                          casts_shadows=True):
+        """visual_server.rs:481-506; the two keyword arguments expose RenderMeshInstance's other fields
+        (:955-962), which the reference sets itself (None / true, and false for sprites)."""
         if asset_server is not None:
             self.asset_server = asset_server
         mid = self.register_mesh(mesh_handle)
         t = to_cols_array(transform)
-        self._check(self.api.set_mesh_instance(self._ctx, int(id), _fp(t), mid))
+        if material_override is None and casts_shadows:
+            self._check(self.api.set_mesh_instance(self._ctx, int(id), _fp(t), mid))
+        else:
+            mat = RND_NONE if material_override is None else int(material_override)
+            self._check(self.api.set_mesh_instance_ex(self._ctx, int(id), _fp(t), mid, mat, 1 if casts_shadows else 0))
 
     def set_sprite(self, id, transform, image_handle, base_color: Color, asset_server=None):
         """visual_server.rs:508-550"""

@@ -18,6 +18,7 @@ _ORACLE_EXTRA = {
     "set_mode": (C.c_int, [_P, C.c_int]),
     "set_threads": (C.c_int, [_P, C.c_int]),
     "get_matrices": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "get_light_cascades": (C.c_int, [_P, C.c_uint64, C.POINTER(C.c_float)]),
     "read_tiles": (C.c_int, [_P, _P]),
 }
 _oracle = None

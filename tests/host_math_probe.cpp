@@ -25,6 +25,15 @@ int main(int argc, char** argv) {
         for (int i = 0; i < 16; ++i) printf("%a ", a[i]);
         printf("\n");
     }
+    // shadow cascades of a directional light pointing along -y + 0.5 z of the camera transform
+    rnd::Mat4 cascades[4];
+    rnd::shadow_cascade_projviews(inv, {-t[4] + 0.5f * t[8], -t[5] + 0.5f * t[9], -t[6] + 0.5f * t[10]}, cascades);
+    for (const auto& m : cascades) {
+        float a[16];
+        m.to_cols_array(a);
+        for (int i = 0; i < 16; ++i) printf("%a ", a[i]);
+        printf("\n");
+    }
     printf("%a %a %a\n", rnd::round_to_f16(0.02f), rnd::round_to_f16(0.04f), rnd::round_to_f16(0.08f));
     return 0;
 }

@@ -30,7 +30,7 @@ def render_pair(scene: SceneDesc, tone=1, materials=None):
     return out
 
 
-def assert_parity(gpu, cpu, min_covered=1, hdr=True):
+def assert_parity(gpu, cpu, min_covered=1, hdr=True, shadow_taps=False):
     cov_g, cov_c = gpu.read_coverage(), cpu.read_coverage()
     assert cov_c.sum() >= min_covered
     assert (cov_g == cov_c).all(), f"coverage differs on {(cov_g != cov_c).sum()} pixels"
@@ -40,10 +40,19 @@ def assert_parity(gpu, cpu, min_covered=1, hdr=True):
     assert (d_g.view(np.uint32) == d_c.view(np.uint32)).all(), f"depth bits differ, max abs {np.abs(d_g - d_c).max()}"
     img_g, img_c = gpu.read_color_rgba8().astype(int), cpu.read_color_rgba8().astype(int)
     diff = np.abs(img_g - img_c).max(axis=-1)
-    assert diff.max() <= 1, f"colour differs by {diff.max()} on {(diff > 1).sum()} pixels"
+    # Under a directional light each of the nine shadow taps is a hard depth comparison: where the
+    # fragment sits within rounding of the occluder depth, the last bits of frag_pos (f32 barycentrics
+    # here, f64 in the oracle) can flip one tap, i.e. 1/9 of that light.  Those pixels count against the
+    # 0.1 % the bar allows (BASELINE.json: <= 1/255 on >= 99.9 % of pixels); everything else is <= 1 LSB.
+    flips = diff > 1
+    if shadow_taps:
+        assert flips.mean() <= 1e-3, f"colour differs by more than 1 LSB on {flips.sum()} of {flips.size} pixels"
+    else:
+        assert diff.max() <= 1, f"colour differs by {diff.max()} on {flips.sum()} pixels"
     if hdr:
         h_g, h_c = gpu.read_color_hdr(), cpu.read_color_hdr()
         rel = np.abs(h_g - h_c) / np.maximum(np.abs(h_c), 1e-3)
+        rel = rel[~flips]
         # the light loop uses v_rcp/v_rsq (1 ulp): the f32 sums differ in the last bits, which can move
         # a value across an f16 rounding boundary: at most one f16 ulp, on a small share of values
         assert rel.max() <= 2 ** -10, f"HDR differs, max rel {rel.max()}"
@@ -80,18 +89,18 @@ def test_triangle_soup_with_clipping(seed):
     # large triangles, many crossing the near plane and the guard band; ragged frame size
     s = soup_scene(seed, 203, 157)
     gpu, cpu = render_pair(s)
-    assert_parity(gpu, cpu, min_covered=2000)
+    assert_parity(gpu, cpu, min_covered=2000, shadow_taps=True)
 
 
 def test_small_triangle_soup():
     s = soup_scene(7, 256, 192, n_meshes=4, n_tri=3000, size=0.03, depth=(2.0, 6.0))
     gpu, cpu = render_pair(s)
-    assert_parity(gpu, cpu, min_covered=1000)
+    assert_parity(gpu, cpu, min_covered=1000, shadow_taps=True)
 
 
 def test_c1_sphere_720p():
     gpu, cpu = render_pair(c1_sphere())
-    assert_parity(gpu, cpu, min_covered=50000)
+    assert_parity(gpu, cpu, min_covered=50000, shadow_taps=True)
 
 
 def test_c2_grid_scaled():
@@ -127,21 +136,21 @@ def test_unlit_alpha_and_tone_mapping_off():
             vs.set_light(9, from_translation((0, 2, -2)), Light.point(8.0).with_color(Color(1, 1, 1, 2.0)))
             vs.render()
             pair.append(vs)
-        assert_parity(pair[0], pair[1], min_covered=500)
+        assert_parity(pair[0], pair[1], min_covered=500, shadow_taps=True)
 
 
 def test_rerender_after_changes_and_resize():
     w, h = 160, 120
     s = soup_scene(11, w, h, n_meshes=2, n_tri=50)
     gpu, cpu = render_pair(s)
-    assert_parity(gpu, cpu, min_covered=500, hdr=False)
+    assert_parity(gpu, cpu, min_covered=500, hdr=False, shadow_taps=True)
     for vs in (gpu, cpu):
         vs.set_render_size((211, 97))
         vs.set_camera(from_translation((0.2, 0.1, -1.5)), Camera(aspect_ratio=211 / 97))
         vs.set_light(50, from_translation((0, 0, 2)), Light.point(3.0).with_color(Color(1, 0.2, 0.2, 3.0)))
         vs.render()
     assert gpu.read_color_rgba8().shape == (97, 211, 4)
-    assert_parity(gpu, cpu, min_covered=500)
+    assert_parity(gpu, cpu, min_covered=500, shadow_taps=True)
     for vs in (gpu, cpu):
         vs.reset_scene()
         vs.render()
@@ -180,3 +189,34 @@ def test_tile_partition_union_equals_single():
         seen += own
     assert (seen == 1).all()
     assert (acc == ref).all()
+
+
+def shadow_scene(w=320, h=200):
+    """A floor, a smaller plate hovering above it, one directional light from above."""
+    s = SceneDesc("shadow", w, h, Camera(aspect_ratio=w / h), from_translation((0, 3, -4)) @ from_rotation_x(0.5))
+    s.meshes.append(Mesh.quad())
+    up = from_rotation_x(math.pi / 2)        # quad normal (0,0,-1) -> (0,1,0)
+    s.instances.append((1, from_translation((0, -1, 3)) @ up @ from_scale((9, 9, 1)), 0))
+    s.instances.append((2, from_translation((0, 0.2, 3)) @ up @ from_scale((1.6, 1.6, 1)), 0))
+    s.lights.append((9, from_rotation_x(1.2), Light.directional().with_color(Color(1.0, 0.9, 0.8, 3.5))))
+    return s
+
+
+def test_directional_shadow_cascades():
+    s = shadow_scene()
+    gpu, cpu = render_pair(s)
+    assert_parity(gpu, cpu, min_covered=15000, shadow_taps=True)
+    # the plate's shadow is there: floor pixels (first two triangles) much darker than the lit floor
+    ids, hdr = cpu.read_triangle_ids(), cpu.read_color_hdr()
+    floor = hdr[ids < 2].sum(axis=-1)
+    lit = np.median(floor)
+    assert (floor < 0.3 * lit).sum() > 200
+    # with the plate not casting, the dark region is gone — on both sides
+    for vs in (gpu, cpu):
+        handles = s.populate(vs)
+        vs.set_mesh_instance(2, s.instances[1][1], handles[0], casts_shadows=False)
+        vs.render()
+    assert_parity(gpu, cpu, min_covered=15000, shadow_taps=True)
+    ids, hdr = cpu.read_triangle_ids(), cpu.read_color_hdr()
+    floor = hdr[ids < 2].sum(axis=-1)
+    assert (floor < 0.3 * np.median(floor)).sum() == 0

@@ -72,8 +72,40 @@ def test_host_math_against_float64(probe, case):
     assert np.allclose(ortho @ [rr, tt, f, 1], [1, 1, 1, 1], atol=1e-5)
 
 
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_shadow_cascades_match_oracle_and_bound_their_slices(probe, case):
+    """compute_shadow_cascade_projviews (visual_server.rs:771-863): product host code == oracle bit for
+    bit, and each cascade's box holds its slice of the camera frustum (x, y in [-1,1], z in [0,1])."""
+    from renderer_amd.types import Light
+    t, cam = CASES[case]
+    mats = run_probe(probe, t, cam)
+    inv, got = mats[3].reshape(4, 4).T.astype(np.float64), mats[6:10]
+    vs = oracle_server(64, 64, threads=1)
+    vs.set_camera(t, cam)
+    tm = np.asarray(t, dtype=np.float32)
+    light_t = np.eye(4, dtype=np.float32)
+    light_t[:3, 2] = -tm[:3, 1] + np.float32(0.5) * tm[:3, 2]      # z axis of the light = direction the probe used
+    vs.set_light(7, light_t, Light.directional())
+    want = np.zeros(64, np.float32)
+    assert vs.api.get_light_cascades(vs._ctx, 7, want.ctypes.data_as(C.POINTER(C.c_float))) == 0
+    for k in range(4):
+        assert (want[16 * k:16 * k + 16].view(np.uint32) == got[k].view(np.uint32)).all(), k
+    ratios = [(0.0, 0.05), (0.05, 0.1), (0.1, 0.3), (0.3, 1.0)]
+    for k, (r0, r1) in enumerate(ratios):
+        m = got[k].reshape(4, 4).T.astype(np.float64)
+        for sx in (-1, 1):
+            for sy in (-1, 1):
+                n = inv @ [sx, sy, 0, 1]; f = inv @ [sx, sy, 1, 1]
+                n, f = n / n[3], f / f[3]
+                for r in (r0, r1):
+                    p = m @ (n + (f - n) * r)
+                    assert abs(p[3] - 1) < 1e-5
+                    assert -1 - 2e-3 <= p[0] <= 1 + 2e-3 and -1 - 2e-3 <= p[1] <= 1 + 2e-3, (k, p)
+                    assert -2e-3 <= p[2] <= 1 + 2e-3, (k, p)
+
+
 def test_f16_clear_colour(probe):
-    line = run_probe(probe, identity(), Camera())[6]
+    line = run_probe(probe, identity(), Camera())[10]
     assert [float(v) for v in line] == [float(np.float16(v)) for v in (0.02, 0.04, 0.08)]
 
 

@@ -351,3 +351,35 @@ def test_ka11_forward_equals_deferred_on_random_scene():
     # HDR: at most a few f16 ulps (one rounding per light pass in the forward target)
     rel = np.abs(d[3] - f[3]) / np.maximum(np.abs(f[3]), 1e-3)
     assert np.percentile(rel, 99.9) < 6 * 2 ** -11
+
+
+def test_ka12_directional_shadow_cascades():
+    """R9 / SURVEY.md 8f N1: a plate above a floor under one directional light darkens the floor
+    below it (compute_light_occlusion, render_mesh.wgsl:184-252); with casts_shadows = false on the
+    plate (RenderMeshInstance, visual_server.rs:961; pipeline3d.rs:303) the floor is evenly lit."""
+    import math
+    from renderer_amd.scenes import SceneDesc
+    from renderer_amd.types import Camera, Color, Light, Mesh, from_rotation_x, from_scale, from_translation
+    w, h = 320, 200
+    s = SceneDesc("shadow", w, h, Camera(aspect_ratio=w / h), from_translation((0, 3, -4)) @ from_rotation_x(0.5))
+    s.meshes.append(Mesh.quad())
+    up = from_rotation_x(math.pi / 2)
+    s.instances.append((1, from_translation((0, -1, 3)) @ up @ from_scale((9, 9, 1)), 0))
+    s.instances.append((2, from_translation((0, 0.2, 3)) @ up @ from_scale((1.6, 1.6, 1)), 0))
+    s.lights.append((9, from_rotation_x(1.2), Light.directional().with_color(Color(1.0, 0.9, 0.8, 3.5))))
+    cpu = oracle_server(w, h, threads=4)
+    handles = s.populate(cpu)
+    cpu.render()
+    ids, hdr = cpu.read_triangle_ids(), cpu.read_color_hdr()
+    floor = hdr[ids < 2].sum(axis=-1)
+    lit = np.median(floor)
+    dark = floor < 0.3 * lit
+    assert 200 < dark.sum() < 2000
+    # fully shadowed floor shows the ambient term only: base * (0.3, 0.5, 0.9) * 0.04, f16-rounded
+    amb = np.float16(np.float32([0.3, 0.5, 0.9]) * np.float32(0.04)).astype(np.float32)
+    assert np.isclose(floor.min(), amb.sum(), rtol=2e-3)
+    cpu.set_mesh_instance(2, s.instances[1][1], handles[0], casts_shadows=False)
+    cpu.render()
+    ids, hdr = cpu.read_triangle_ids(), cpu.read_color_hdr()
+    floor = hdr[ids < 2].sum(axis=-1)
+    assert (floor < 0.3 * np.median(floor)).sum() == 0
