@@ -136,7 +136,10 @@ int rnd_register_texture(rnd_ctx* ctx, uint32_t texture_id, uint32_t width, uint
 int rnd_set_camera(rnd_ctx* ctx, const float transform_cols[16], float vfov, float aspect_ratio,
                    float z_near, float z_far);
 /* reference: set_light(UniqueNodeId, Affine3A, &Light) :350-474; color.a is the intensity;
- * radius is ignored for directional lights (Light::radius().unwrap_or_default()). */
+ * radius is ignored for directional lights (Light::radius().unwrap_or_default()).
+ * A directional light's four shadow cascades (compute_shadow_cascade_projviews :771-863) are
+ * computed here, from the camera current at this call, as create_light/update_light do
+ * (:380-381, :445-446); rnd_set_camera does not recompute them (:221). */
 int rnd_set_light(rnd_ctx* ctx, uint64_t id, const float transform_cols[16], const float color[4],
                   uint32_t kind, float radius);
 /* reference: set_mesh_instance(UniqueNodeId, Affine3A, Handle<Mesh>, &AssetServer) :481-506
