@@ -58,7 +58,12 @@ struct Vertex { V3 pos, nrm; float u, v; };
 struct Submesh { std::vector<Vertex> verts; std::vector<uint32_t> idx; uint32_t material; };
 struct Mesh { std::vector<Submesh> subs; };
 struct Material { float base[4]; uint32_t billboard, unlit, texture; };
-struct Texture { uint32_t w, h, mips; std::vector<uint8_t> data; };
+struct Texture {
+    uint32_t w, h, mips;
+    std::vector<float> texels;          // all levels, RGBA f32, sRGB-decoded rgb (Rgba8UnormSrgb, backend.rs:376)
+    std::vector<size_t> level_offset;   // in texels
+    bool opaque;                        // every alpha == 255
+};
 struct Light {
     uint64_t id; M4 transform; float color[4]; uint32_t kind; float radius;
     M4 cascades[4];                 // world -> light clip of the four shadow cascades, as of set_light
@@ -226,8 +231,10 @@ static void raster_triangle(const V4& c0, const V4& c1, const V4& c2, uint32_t W
 
 // Perspective-correct barycentrics of pixel (i,j) w.r.t. the ORIGINAL clip-space triangle, by 2D
 // homogeneous edge functions in f64 (valid for vertices with w <= 0 too).
+// db_dx / db_dy (optional): derivatives of the barycentrics per PIXEL step in x / y, from the same
+// affine edge functions (e_i = a_i*xn + b_i*yn + c_i, b_i = e_i / S): d(e_i/S) = (de_i*S - e_i*dS)/S^2.
 static inline void barycentrics(const V4& c0, const V4& c1, const V4& c2, uint32_t i, uint32_t j,
-                                uint32_t W, uint32_t H, float b[3]) {
+                                uint32_t W, uint32_t H, float b[3], float* db_dx = nullptr, float* db_dy = nullptr) {
     double x0 = c0.x, y0 = c0.y, w0 = c0.w, x1 = c1.x, y1 = c1.y, w1 = c1.w, x2 = c2.x, y2 = c2.y,
            w2 = c2.w;
     double xn = ((double)i + 0.5) * (2.0 / (double)W) - 1.0;
@@ -238,8 +245,22 @@ static inline void barycentrics(const V4& c0, const V4& c1, const V4& c2, uint32
     double e2 = ((y0 * w1 - w0 * y1) * xn + (w0 * x1 - x0 * w1) * yn) + (x0 * y1 - y0 * x1);
     double inv_s = 1.0 / ((e0 + e1) + e2);
     double b0 = e0 * inv_s, b1 = e1 * inv_s, b2 = e2 * inv_s;
-    if (!(std::isfinite(b0) && std::isfinite(b1) && std::isfinite(b2))) { b0 = 1.0; b1 = 0.0; b2 = 0.0; }
+    bool ok = std::isfinite(b0) && std::isfinite(b1) && std::isfinite(b2);
+    if (!ok) { b0 = 1.0; b1 = 0.0; b2 = 0.0; }
     b[0] = (float)b0; b[1] = (float)b1; b[2] = (float)b2;
+    if (db_dx && db_dy) {
+        const double ax[3] = {y1 * w2 - w1 * y2, y2 * w0 - w2 * y0, y0 * w1 - w0 * y1};
+        const double ay[3] = {w1 * x2 - x1 * w2, w2 * x0 - x2 * w0, w0 * x1 - x0 * w1};
+        const double e[3] = {e0, e1, e2};
+        const double s = (e0 + e1) + e2, sax = (ax[0] + ax[1]) + ax[2], say = (ay[0] + ay[1]) + ay[2];
+        const double step_x = 2.0 / (double)W, step_y = -2.0 / (double)H;
+        for (int k = 0; k < 3; ++k) {
+            double dx = (ax[k] * s - e[k] * sax) * (inv_s * inv_s) * step_x;
+            double dy = (ay[k] * s - e[k] * say) * (inv_s * inv_s) * step_y;
+            db_dx[k] = ok && std::isfinite(dx) ? (float)dx : 0.0f;
+            db_dy[k] = ok && std::isfinite(dy) ? (float)dy : 0.0f;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -318,7 +339,7 @@ static V4 vertex_clip(const M4& pv, const M4& model, const M4& cam, uint32_t bil
     return mul(pv, mul_point(model, pos));
 }
 
-struct Frag { V3 pos, nrm; float u, v; };
+struct Frag { V3 pos, nrm; float u, v; float dudx = 0, dvdx = 0, dudy = 0, dvdy = 0; };
 
 // fragment inputs by the deferred formulation: interpolate in object space, transform once
 static Frag frag_deferred(const DrawItem& it, const M4& cam, uint32_t t, const float b[3]) {
@@ -382,9 +403,52 @@ static Frag frag_forward(const DrawItem& it, const M4& cam, uint32_t t, const fl
 
 // base = material.base_color * textureSample(...) (render_mesh.wgsl:89, :142); untextured
 // materials bind the 1x1 white texture (visual_server.rs:736).
-static void base_color(const Ctx& c, const Material& m, float /*u*/, float /*v*/, float out[4]) {
-    (void)c;
-    for (int k = 0; k < 4; ++k) out[k] = m.base[k] * 1.0f;
+// textureSample with the reference's "filtered" sampler (backend.rs:414-426): Repeat addressing,
+// linear mag/min/mip.  Restated from the WebGPU/Vulkan rules, isotropic (anisotropy 16 is
+// implementation-defined and not modelled): rho = the longer of the two pixel footprints in texels,
+// lambda = log2(rho) clamped to [0, mips-1]; bilinear taps at floor(x - 0.5), weights
+// a*(1-t) + b*t; two levels blended by frac(lambda).
+static void bilinear(const Texture& t, uint32_t level, float u, float v, float out[4]) {
+    const uint32_t wl = std::max(1u, t.w >> level), hl = std::max(1u, t.h >> level);
+    const float x = u * (float)wl - 0.5f, y = v * (float)hl - 0.5f;
+    const float xf = std::floor(x), yf = std::floor(y);
+    const float fx = x - xf, fy = y - yf;
+    auto wrap = [](float f, uint32_t n) {
+        long long k = (long long)f % (long long)n;
+        return (uint32_t)(k < 0 ? k + n : k);
+    };
+    const uint32_t x0 = wrap(xf, wl), x1 = wrap(xf + 1.0f, wl), y0 = wrap(yf, hl), y1 = wrap(yf + 1.0f, hl);
+    const float* base = t.texels.data() + 4 * t.level_offset[level];
+    const float* t00 = base + 4 * ((size_t)y0 * wl + x0), *t10 = base + 4 * ((size_t)y0 * wl + x1);
+    const float* t01 = base + 4 * ((size_t)y1 * wl + x0), *t11 = base + 4 * ((size_t)y1 * wl + x1);
+    for (int k = 0; k < 4; ++k) {
+        float top = t00[k] * (1.0f - fx) + t10[k] * fx, bot = t01[k] * (1.0f - fx) + t11[k] * fx;
+        out[k] = top * (1.0f - fy) + bot * fy;
+    }
+}
+static void sample_texture(const Texture& t, const Frag& f, float out[4]) {
+    const float ax = f.dudx * (float)t.w, ay = f.dvdx * (float)t.h, bx = f.dudy * (float)t.w, by = f.dvdy * (float)t.h;
+    const float rho2 = std::fmax(ax * ax + ay * ay, bx * bx + by * by);
+    float lambda = 0.5f * std::log2(rho2);                     // log2(sqrt(rho2)); -inf for a constant uv
+    lambda = std::isnan(lambda) ? 0.0f : clampf(lambda, 0.0f, (float)(t.mips - 1));
+    const float lf = std::floor(lambda), frac = lambda - lf;
+    const uint32_t l0 = (uint32_t)lf, l1 = std::min(l0 + 1, t.mips - 1);
+    float a[4], b[4];
+    bilinear(t, l0, f.u, f.v, a);
+    if (frac > 0.0f) {
+        bilinear(t, l1, f.u, f.v, b);
+        for (int k = 0; k < 4; ++k) out[k] = a[k] * (1.0f - frac) + b[k] * frac;
+    } else {
+        for (int k = 0; k < 4; ++k) out[k] = a[k];
+    }
+}
+static void base_color(const Ctx& c, const Material& m, const Frag* f, float out[4]) {
+    float texel[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+    if (m.texture != RND_NONE && f) {
+        auto it = c.textures.find(m.texture);
+        if (it != c.textures.end()) sample_texture(it->second, *f, texel);
+    }
+    for (int k = 0; k < 4; ++k) out[k] = m.base[k] * texel[k];
 }
 
 // compute_light_blinn_phong (render_mesh.wgsl:256-276) with shininess 8
@@ -621,7 +685,7 @@ static int render(Ctx& c) {
     for (size_t k = 0; k < P; ++k) vis[k].store(CLEAR_KEY, std::memory_order_relaxed);
     for (const DrawItem& it : items) {
         float bc[4];
-        base_color(c, it.mat, 0, 0, bc);
+        base_color(c, it.mat, nullptr, bc);     // textures are opaque (register_texture), so alpha is the material's
         if (bc[3] < 0.5f) continue;
         const Submesh& s = *it.sub;
         size_t ntri = s.idx.size() / 3;
@@ -650,6 +714,9 @@ static int render(Ctx& c) {
         size_t k = std::upper_bound(tri_bases.begin(), tri_bases.end(), id) - tri_bases.begin();
         return k - 1;
     };
+    if (c.mode != 0)
+        for (const DrawItem& it : items)
+            if (it.mat.texture != RND_NONE) { c.err = "the forward restatement covers untextured materials only"; return RND_ERR_UNSUPPORTED; }
     if (c.mode == 0) {
         parallel_for(c.threads, H, [&](size_t lo, size_t hi) {
             for (size_t j = lo; j < hi; ++j)
@@ -663,12 +730,17 @@ static int render(Ctx& c) {
                         const DrawItem& it = items[item_of(id)];
                         uint32_t t = id - it.tri_base;
                         const Submesh& s = *it.sub;
-                        float b[3];
+                        float b[3], dbx[3], dby[3];
                         barycentrics(it.clip[s.idx[3 * t]], it.clip[s.idx[3 * t + 1]], it.clip[s.idx[3 * t + 2]],
-                                     i, (uint32_t)j, W, H, b);
+                                     i, (uint32_t)j, W, H, b, dbx, dby);
                         Frag f = frag_deferred(it, c.cam, t, b);
+                        {   // screen-space uv derivatives for the mip level, analytic from the barycentrics'
+                            const Vertex& va = s.verts[s.idx[3 * t]], &vb = s.verts[s.idx[3 * t + 1]], &vc = s.verts[s.idx[3 * t + 2]];
+                            f.dudx = (dbx[0] * va.u + dbx[1] * vb.u) + dbx[2] * vc.u; f.dvdx = (dbx[0] * va.v + dbx[1] * vb.v) + dbx[2] * vc.v;
+                            f.dudy = (dby[0] * va.u + dby[1] * vb.u) + dby[2] * vc.u; f.dvdy = (dby[0] * va.v + dby[1] * vb.v) + dby[2] * vc.v;
+                        }
                         float bc[4];
-                        base_color(c, it.mat, f.u, f.v, bc);
+                        base_color(c, it.mat, &f, bc);
                         V3 base{bc[0], bc[1], bc[2]};
                         V3 col = base;
                         if (!it.mat.unlit) {
@@ -692,7 +764,7 @@ static int render(Ctx& c) {
             if (id == RND_NONE) { hdr[0] = clear[0]; hdr[1] = clear[1]; hdr[2] = clear[2]; continue; }
             const DrawItem& it = items[item_of(id)];
             float bc[4];
-            base_color(c, it.mat, 0, 0, bc);
+            base_color(c, it.mat, nullptr, bc);
             V3 base{bc[0], bc[1], bc[2]};
             V3 col = base;
             if (!it.mat.unlit) col = base * (V3{c.ambient[0], c.ambient[1], c.ambient[2]} * c.ambient[3]);
@@ -702,7 +774,7 @@ static int render(Ctx& c) {
         // (pipeline3d.rs:346-367, :507-513, :561-575)
         for (const DrawItem& it : items) {
             float bc0[4];
-            base_color(c, it.mat, 0, 0, bc0);
+            base_color(c, it.mat, nullptr, bc0);
             if (bc0[3] < 0.5f || it.mat.unlit) continue;
             const Submesh& s = *it.sub;
             for (const Light& l : c.lights) {
@@ -716,7 +788,7 @@ static int render(Ctx& c) {
                         barycentrics(c0, c1, c2, i, j, W, H, b);
                         Frag f = frag_forward(it, c.cam, (uint32_t)t, b);
                         float bc[4];
-                        base_color(c, it.mat, f.u, f.v, bc);
+                        base_color(c, it.mat, nullptr, bc);
                         V3 contrib;
                         if (!light_contribution(c, l, f, V3{bc[0], bc[1], bc[2]}, contrib)) return;
                         float* hdr = &c.hdr[p * 3];
@@ -822,8 +894,29 @@ int orc_register_material(rnd_ctx* ctx, uint32_t id, const float base[4], uint32
     c->materials[id] = orc::Material{{base[0], base[1], base[2], base[3]}, billboard, unlit ? 1u : 0u, tex};
     return RND_OK;
 }
-int orc_register_texture(rnd_ctx* ctx, uint32_t, uint32_t, uint32_t, uint32_t, const uint8_t*) {
-    CTX(ctx)->err = "textures not built yet (SURVEY §8f N2)"; return RND_ERR_UNSUPPORTED;
+int orc_register_texture(rnd_ctx* ctx, uint32_t id, uint32_t w, uint32_t h, uint32_t mips, const uint8_t* data) {
+    Ctx* c = CTX(ctx);
+    if (id == RND_NONE || !w || !h || !mips || !data || w > 16384 || h > 16384) { c->err = "bad texture"; return RND_ERR_INVALID; }
+    uint32_t max_levels = 1;
+    while ((std::max(w, h) >> max_levels) != 0) ++max_levels;
+    if (mips > max_levels) { c->err = "more mip levels than the size allows"; return RND_ERR_INVALID; }
+    orc::Texture t;
+    t.w = w; t.h = h; t.mips = mips; t.opaque = true;
+    size_t total = 0;
+    for (uint32_t l = 0; l < mips; ++l) { t.level_offset.push_back(total); total += (size_t)std::max(1u, w >> l) * std::max(1u, h >> l); }
+    t.texels.resize(total * 4);
+    for (size_t k = 0; k < total; ++k) {
+        for (int ch = 0; ch < 3; ++ch) {                       // sRGB EOTF, evaluated in f64 and rounded once
+            double v = data[4 * k + ch] / 255.0;
+            double lin = v <= 0.04045 ? v / 12.92 : std::pow((v + 0.055) / 1.055, 2.4);
+            t.texels[4 * k + ch] = (float)lin;
+        }
+        t.texels[4 * k + 3] = (float)(data[4 * k + 3] / 255.0);
+        if (data[4 * k + 3] != 255) t.opaque = false;
+    }
+    if (!t.opaque) { c->err = "textures with alpha below 1 (per-fragment alpha test) are not built yet (SURVEY 8f N2)"; return RND_ERR_UNSUPPORTED; }
+    c->textures[id] = std::move(t);
+    return RND_OK;
 }
 
 int orc_set_camera(rnd_ctx* ctx, const float t[16], float vfov, float aspect, float zn, float zf) {

@@ -83,6 +83,15 @@ struct ShadowSet {
     const uint64_t* layers[kShadowCascades];
 };
 
+// One registered texture as the shading kernel samples it: every mip level as RGBA f32 (rgb already
+// through the sRGB EOTF — the reference's Rgba8UnormSrgb view, backend.rs:376), levels packed
+// largest first, level l being max(1, width >> l) x max(1, height >> l).
+struct TextureDesc {
+    const float* texels;
+    uint32_t width, height, mips, pad;
+};
+static_assert(sizeof(TextureDesc) == 24, "TextureDesc layout");
+
 // Per-frame constants passed by value to the kernels.
 struct FrameConst {
     float pv[16];          // projection * view (render_mesh.wgsl:48)

@@ -18,6 +18,7 @@ struct FrameBuffers {
     const uint32_t* tri_bases;      // n_items + 1
     const GpuLight* lights;
     const ShadowSet* shadow_sets;   // indexed by GpuLight::shadow_index
+    const TextureDesc* textures;    // indexed by DrawItem::texture
     const uint32_t* unit_bases;     // n_items + 1: first work unit of each item
     uint2* active_units;            // (item, chunk) of the work units that survived k_cull
     uint32_t* vblock_needed;        // per kVertexBlock block of the frame's vertex slots: used by a surviving unit

@@ -865,6 +865,43 @@ __device__ __forceinline__ uint32_t srgb8_f(float lin) {
 #endif
 }
 
+// textureSample with the reference's "filtered" sampler (backend.rs:414-426: Repeat, linear
+// mag/min/mip), restated isotropically as in the oracle: rho = longer pixel footprint in texels,
+// lambda = log2(rho) clamped to [0, mips-1], bilinear taps at floor(x - 0.5), two levels blended.
+__device__ __forceinline__ f32x4 texture_bilinear(const TextureDesc& t, uint32_t level, float u, float v) {
+    const uint32_t wl = max(1u, t.width >> level), hl = max(1u, t.height >> level);
+    size_t off = 0;
+    for (uint32_t l = 0; l < level; ++l) off += (size_t)max(1u, t.width >> l) * max(1u, t.height >> l);
+    const float x = u * (float)wl - 0.5f, y = v * (float)hl - 0.5f;
+    const float xf = floorf(x), yf = floorf(y);
+    const float fx = x - xf, fy = y - yf;
+    auto wrap = [](float f, uint32_t n) {
+        long long k = (long long)f % (long long)n;
+        return (uint32_t)(k < 0 ? k + (long long)n : k);
+    };
+    const uint32_t x0 = wrap(xf, wl), x1 = wrap(xf + 1.0f, wl), y0 = wrap(yf, hl), y1 = wrap(yf + 1.0f, hl);
+    gptr_f32x4 base = (gptr_f32x4)t.texels + off;
+    const f32x4 t00 = base[(size_t)y0 * wl + x0], t10 = base[(size_t)y0 * wl + x1];
+    const f32x4 t01 = base[(size_t)y1 * wl + x0], t11 = base[(size_t)y1 * wl + x1];
+    const f32x4 top = t00 * (1.0f - fx) + t10 * fx, bot = t01 * (1.0f - fx) + t11 * fx;
+    return top * (1.0f - fy) + bot * fy;
+}
+__device__ __forceinline__ f32x4 texture_sample(const TextureDesc& t, float u, float v, float dudx, float dvdx,
+                                                float dudy, float dvdy) {
+    const float ax = dudx * (float)t.width, ay = dvdx * (float)t.height, bx = dudy * (float)t.width, by = dvdy * (float)t.height;
+    const float rho2 = fmaxf(ax * ax + ay * ay, bx * bx + by * by);
+    float lambda = 0.5f * log2f(rho2);
+    lambda = (lambda != lambda) ? 0.0f : fminf(fmaxf(lambda, 0.0f), (float)(t.mips - 1u));
+    const float lf = floorf(lambda), frac = lambda - lf;
+    const uint32_t l0 = (uint32_t)lf, l1 = min(l0 + 1u, t.mips - 1u);
+    f32x4 a = texture_bilinear(t, l0, u, v);
+    if (frac > 0.0f) {
+        const f32x4 b = texture_bilinear(t, l1, u, v);
+        a = a * (1.0f - frac) + b * frac;
+    }
+    return a;
+}
+
 // Monotone map f32 -> u32 (and back) so float min/max run as integer min/max over DPP row
 // rotations: no NaN canonicalization, one instruction per step.
 __device__ __forceinline__ uint32_t f32_ordered(float f) {
@@ -898,8 +935,8 @@ struct PixelInputs {
 // `d` is wave-uniform (the caller waterfalls over the items of the wave), so its fields come in
 // through scalar loads; per pixel only the index triple and the three 32-byte vertices are gathered.
 __device__ __forceinline__ void prepare_pixel(const DrawItem& d, const FrameConst& fc, const float4* __restrict__ clip,
-                                              uint32_t id, uint32_t i, uint32_t j, PixelInputs& o,
-                                              FrameCounters* counters) {
+                                              const TextureDesc* __restrict__ textures, uint32_t id, uint32_t i,
+                                              uint32_t j, PixelInputs& o, FrameCounters* counters) {
     // straight-line: an index that would leave its buffer is clamped and reported, not branched on
     uint32_t t = id - d.tri_base;
     bool ok = t < d.n_tris;
@@ -966,8 +1003,33 @@ __device__ __forceinline__ void prepare_pixel(const DrawItem& d, const FrameCons
     float gx = (q[0] * nx + q[4] * ny) + q[8] * nz;
     float gy = (q[1] * nx + q[5] * ny) + q[9] * nz;
     float gz = (q[2] * nx + q[6] * ny) + q[10] * nz;
-    // base colour (untextured: the 1x1 white texture)
-    o.br = d.base_color[0] * 1.0f; o.bg = d.base_color[1] * 1.0f; o.bb = d.base_color[2] * 1.0f;
+    // base colour = material.base_color * textureSample(...) (render_mesh.wgsl:89, :142); untextured
+    // materials bind the 1x1 white texture (visual_server.rs:736)
+    float tr = 1.0f, tg = 1.0f, tb = 1.0f;
+    if (d.texture != RND_NONE) {        // uniform over the wave (d is)
+        const float u0 = a1.z, v0 = a1.w, u1 = b1v.z, v1 = b1v.w, u2 = c1v.z, v2 = c1v.w;
+        const float uu = (b0 * u0 + b1 * u1) + b2 * u2, vv = (b0 * v0 + b1 * v1) + b2 * v2;
+        // screen-space uv derivatives for the mip level, analytic: the edge functions are affine in
+        // the pixel centre, b_k = e_k / S, so d b_k = (d e_k * S - e_k * dS) / S^2
+        const float txn = fmaf((float)i + 0.5f, fc.ndc_step_xf, -1.0f), tyn = fmaf(-((float)j + 0.5f), fc.ndc_step_yf, 1.0f);
+        const float px0 = fmaf(-txn, c0.w, c0.x), py0 = fmaf(-tyn, c0.w, c0.y);
+        const float px1 = fmaf(-txn, c1.w, c1.x), py1 = fmaf(-tyn, c1.w, c1.y);
+        const float px2 = fmaf(-txn, c2.w, c2.x), py2 = fmaf(-tyn, c2.w, c2.y);
+        const float f0 = fmaf(px1, py2, -(px2 * py1)), f1 = fmaf(px2, py0, -(px0 * py2)), f2 = fmaf(px0, py1, -(px1 * py0));
+        const float ax0 = c2.w * py1 - c1.w * py2, ax1 = c0.w * py2 - c2.w * py0, ax2 = c1.w * py0 - c0.w * py1;
+        const float ay0 = px2 * c1.w - px1 * c2.w, ay1 = px0 * c2.w - px2 * c0.w, ay2 = px1 * c0.w - px0 * c1.w;
+        const float S = (f0 + f1) + f2, Sx = (ax0 + ax1) + ax2, Sy = (ay0 + ay1) + ay2;
+        const float is = 1.0f / S, is2 = is * is;
+        const float kx = is2 * fc.ndc_step_xf, ky = is2 * (-fc.ndc_step_yf);
+        float dx0 = (ax0 * S - f0 * Sx) * kx, dx1 = (ax1 * S - f1 * Sx) * kx, dx2 = (ax2 * S - f2 * Sx) * kx;
+        float dy0 = (ay0 * S - f0 * Sy) * ky, dy1 = (ay1 * S - f1 * Sy) * ky, dy2 = (ay2 * S - f2 * Sy) * ky;
+        if (!(fabsf(dx0) + fabsf(dx1) + fabsf(dx2) + fabsf(dy0) + fabsf(dy1) + fabsf(dy2) < 3.0e38f)) dx0 = dx1 = dx2 = dy0 = dy1 = dy2 = 0.0f;
+        const float dudx = (dx0 * u0 + dx1 * u1) + dx2 * u2, dvdx = (dx0 * v0 + dx1 * v1) + dx2 * v2;
+        const float dudy = (dy0 * u0 + dy1 * u1) + dy2 * u2, dvdy = (dy0 * v0 + dy1 * v1) + dy2 * v2;
+        const f32x4 texel = texture_sample(textures[d.texture], uu, vv, dudx, dvdx, dudy, dvdy);
+        tr = texel.x; tg = texel.y; tb = texel.z;
+    }
+    o.br = d.base_color[0] * tr; o.bg = d.base_color[1] * tg; o.bb = d.base_color[2] * tb;
     o.lit = !(d.flags & kItemUnlit);
     if (o.lit) {
         float ar = fc.ambient[0] * fc.ambient[3], ag = fc.ambient[1] * fc.ambient[3], ab = fc.ambient[2] * fc.ambient[3];
@@ -1176,7 +1238,7 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(
             if (__ballot(covered[k] && it != lead) == 0ull) {
                 // the usual case: every covered pixel of the wave belongs to one draw item
                 const DrawItem d = load_item_uniform(fb.items, lead_s);
-                if (covered[k]) prepare_pixel(d, fc, fb.clip, id, i, j, px[k], fb.counters);
+                if (covered[k]) prepare_pixel(d, fc, fb.clip, fb.textures, id, i, j, px[k], fb.counters);
             } else if (covered[k]) {
                 // waterfall: one pass per distinct draw item among the wave's pixels
                 for (unsigned long long pending = __ballot(true); pending;) {
@@ -1185,7 +1247,7 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(
                     pending &= ~__ballot(mine);
                     if (mine) {
                         const DrawItem d = load_item_uniform(fb.items, cur_s);
-                        prepare_pixel(d, fc, fb.clip, id, i, j, px[k], fb.counters);
+                        prepare_pixel(d, fc, fb.clip, fb.textures, id, i, j, px[k], fb.counters);
                     }
                 }
             }

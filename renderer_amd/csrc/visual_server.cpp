@@ -74,6 +74,8 @@ VisualServer::~VisualServer() {
     d_items_.release(); d_vert_bases_.release(); d_tri_bases_.release(); d_lights_.release(); d_clip_.release();
     d_records_.release(); d_tilewords_.release(); d_clip_queue_.release(); d_chunk_count_.release(); d_unit_bases_.release(); d_vblock_needed_.release(); d_active_units_.release(); d_tile_count_.release();
     d_tile_offset_.release(); d_tile_cursor_.release(); d_entries_.release(); d_counters_.release();
+    for (auto& kv : textures_) kv.second.texels.release();
+    d_textures_.release();
     d_shadow_items_.release(); d_shadow_sets_.release(); d_shadow_order_.release();
     for (auto& b : shadow_layers_) b.release();
     d_launch_order_.release(); d_vis_.release(); d_frame_.release(); d_tiles_.release(); d_packed_.release();
@@ -221,11 +223,51 @@ void VisualServer::register_mesh(uint32_t mesh_id, uint32_t n_submeshes, const r
 
 void VisualServer::register_material(uint32_t id, const Material& m) {
     if (id == RND_NONE || m.billboard_mode > 2) throw Error(RND_ERR_INVALID, "bad material");
-    if (m.texture != RND_NONE) throw Error(RND_ERR_UNSUPPORTED, "textured materials not built yet (SURVEY §8f N2)");
+    if (m.texture != RND_NONE && !textures_.count(m.texture)) throw Error(RND_ERR_UNKNOWN_ID, "texture id not registered");
     materials_[id] = m;
 }
-void VisualServer::register_texture(uint32_t, uint32_t, uint32_t, uint32_t, const uint8_t*) {
-    throw Error(RND_ERR_UNSUPPORTED, "textures not built yet (SURVEY §8f N2)");
+// register_texture / update_texture (visual_server.rs:752-769): an Rgba8UnormSrgb texture with the
+// caller's mip chain (backend.rs:358-383).  Stored decoded: RGBA f32 per texel, rgb through the sRGB
+// EOTF (evaluated in f64, rounded once), so the shading kernel filters linear values as the
+// hardware sampler does.  Textures with any alpha below 255 would need the per-fragment alpha test
+// (render_mesh.wgsl:91) in the raster stage: not built yet.
+void VisualServer::register_texture(uint32_t id, uint32_t w, uint32_t h, uint32_t mips, const uint8_t* data) {
+    if (id == RND_NONE || !w || !h || !mips || !data || w > 16384 || h > 16384) throw Error(RND_ERR_INVALID, "bad texture");
+    uint32_t max_levels = 1;
+    while ((std::max(w, h) >> max_levels) != 0) ++max_levels;
+    if (mips > max_levels) throw Error(RND_ERR_INVALID, "more mip levels than the size allows");
+    size_t total = 0;
+    for (uint32_t l = 0; l < mips; ++l) total += (size_t)std::max(1u, w >> l) * std::max(1u, h >> l);
+    std::vector<float> texels(total * 4);
+    double lut[256];
+    for (int v = 0; v < 256; ++v) {
+        const double c = v / 255.0;
+        lut[v] = c <= 0.04045 ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4);
+    }
+    for (size_t k = 0; k < total; ++k) {
+        if (data[4 * k + 3] != 255)
+            throw Error(RND_ERR_UNSUPPORTED, "textures with alpha below 1 (per-fragment alpha test) are not built yet (SURVEY 8f N2)");
+        texels[4 * k + 0] = (float)lut[data[4 * k + 0]];
+        texels[4 * k + 1] = (float)lut[data[4 * k + 1]];
+        texels[4 * k + 2] = (float)lut[data[4 * k + 2]];
+        texels[4 * k + 3] = 1.0f;
+    }
+    use_device();
+    finish();
+    RenderTexture& t = textures_[id];
+    const bool is_new = t.mips == 0;
+    t.texels.ensure(texels.size());
+    HIP_CHECK(hipMemcpy(t.texels.ptr, texels.data(), texels.size() * sizeof(float), hipMemcpyHostToDevice));
+    t.width = w; t.height = h; t.mips = mips;
+    if (is_new) t.slot = (uint32_t)textures_.size() - 1;
+    upload_texture_table();
+}
+
+void VisualServer::upload_texture_table() {
+    std::vector<TextureDesc> table(std::max<size_t>(textures_.size(), 1), TextureDesc{nullptr, 0, 0, 0, 0});
+    for (const auto& kv : textures_) table.at(kv.second.slot) = TextureDesc{kv.second.texels.ptr, kv.second.width, kv.second.height, kv.second.mips, 0};
+    d_textures_.ensure(table.size());
+    HIP_CHECK(hipMemcpy(d_textures_.ptr, table.data(), table.size() * sizeof(TextureDesc), hipMemcpyHostToDevice));
 }
 
 // ---- per-frame state -------------------------------------------------------------------------
@@ -261,7 +303,7 @@ void VisualServer::set_mesh_instance(UniqueNodeId id, const Mat4& transform, uin
 }
 
 void VisualServer::set_sprite(UniqueNodeId id, const Mat4& transform, uint32_t texture_id, const float color[4]) {
-    if (texture_id != RND_NONE) throw Error(RND_ERR_UNSUPPORTED, "textured sprites not built yet (SURVEY §8f N2)");
+    if (texture_id != RND_NONE && !textures_.count(texture_id)) throw Error(RND_ERR_UNKNOWN_ID, "texture id not registered");
     uint32_t mid;
     auto it = sprite_materials_.find(id);
     if (it == sprite_materials_.end()) { mid = next_sprite_material_++; sprite_materials_[id] = mid; }
@@ -281,6 +323,8 @@ void VisualServer::reset_scene() {
         for (auto& s : it->second.submeshes) { s.vertex_buffer.release(); s.positions.release(); s.index_buffer.release(); s.chunks.release(); }
         it = meshes_.erase(it);
     }
+    for (auto& kv : textures_) kv.second.texels.release();
+    textures_.clear();
     materials_.clear(); lights_.clear(); mesh_instances_.clear(); sprite_materials_.clear();
 }
 
@@ -324,7 +368,12 @@ void VisualServer::build_frame(std::vector<DrawItem>& items, std::vector<uint32_
             std::memcpy(d.base_color, mat.base_color, 16);
             d.flags = mat.billboard_mode | (mat.unlit ? kItemUnlit : 0u) | (inst.casts_shadows ? kItemCastsShadows : 0u);
             if (mat.base_color[3] * 1.0f < 0.5f) d.flags |= kItemSkip;   // alpha test, untextured (render_mesh.wgsl:91)
-            d.texture = mat.texture;
+            d.texture = RND_NONE;
+            if (mat.texture != RND_NONE) {
+                auto tex = textures_.find(mat.texture);
+                if (tex == textures_.end()) throw Error(RND_ERR_UNKNOWN_ID, "texture id not registered");
+                d.texture = tex->second.slot;
+            }
             d.chunks = s.chunks.ptr; d.n_chunks = s.n_chunks; d.unit_base = (uint32_t)unit_base;
             vert_bases.push_back(d.vert_base);
             tri_bases.push_back(d.tri_base);
@@ -482,6 +531,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
 
     FrameBuffers fb{};
     fb.items = d_items_.ptr; fb.vert_bases = d_vert_bases_.ptr; fb.tri_bases = d_tri_bases_.ptr; fb.lights = d_lights_.ptr;
+    fb.textures = d_textures_.ptr;
     fb.shadow_sets = n_sets ? d_shadow_sets_.ptr : nullptr;      // null selects the shading kernel without the lookup
     fb.clip = d_clip_.ptr; fb.records = d_records_.ptr; fb.tilewords = reinterpret_cast<uint2*>(d_tilewords_.ptr); fb.clip_queue = d_clip_queue_.ptr;
     fb.chunk_count = d_chunk_count_.ptr;

@@ -59,6 +59,11 @@ struct RenderSubmesh {           // visual_server.rs:948-953
     uint32_t material = RND_NONE;
 };
 struct RenderMesh { std::vector<RenderSubmesh> submeshes; };
+struct RenderTexture {           // RenderScene::textures (visual_server.rs:901) as decoded RGBA f32 levels
+    DeviceBuffer<float> texels;
+    uint32_t width = 0, height = 0, mips = 0;
+    uint32_t slot = 0;           // index into the device texture table
+};
 struct RenderLight {
     UniqueNodeId id; Mat4 transform; Light light;
     Mat4 cascades[4];     // RenderShadowCascade::projview x4 (visual_server.rs:380-405), as of the last set_light
@@ -165,6 +170,9 @@ private:
     // RenderScene — visual_server.rs:896-905 (insertion-ordered instead of HashMap order)
     std::unordered_map<uint32_t, RenderMesh> meshes_;
     std::unordered_map<uint32_t, Material> materials_;
+    std::unordered_map<uint32_t, RenderTexture> textures_;
+    DeviceBuffer<TextureDesc> d_textures_;
+    void upload_texture_table();
     std::vector<RenderLight> lights_;
     std::vector<RenderMeshInstance> mesh_instances_;
     std::unordered_map<UniqueNodeId, uint32_t> sprite_materials_;

@@ -69,6 +69,55 @@ class BillboardMode:
 
 
 @dataclass
+class Image:
+    """crates/asset_image/src/image.rs:8-113 — RGBA8 (sRGB) pixels, optionally with the mip chain
+    `make_mips` builds; `data` is what `Image::data()` hands to `create_color_texture`
+    (visual_server.rs:760-768): the levels tightly packed, largest first."""
+    width: int
+    height: int
+    pixels: np.ndarray                      # (height, width, 4) uint8, level 0
+    mips: Optional[np.ndarray] = None       # packed chain, set by make_mips
+    level_count: int = 1
+
+    def __post_init__(self):
+        self.pixels = np.ascontiguousarray(np.asarray(self.pixels, dtype=np.uint8).reshape(self.height, self.width, 4))
+
+    def make_mips(self):
+        """image.rs:34-92 with downsample_bilinear :122-186: square power-of-two images only; each level
+        is the 2x2 box average of the one above, taken in a gamma-2.0 approximation of linear light
+        ((c/255)^2, mean, sqrt, truncated to u8); alpha averaged linearly."""
+        if self.width != self.height or self.width & (self.width - 1):
+            raise ValueError(f"can't generate mipmaps on images that aren't square and that have non power of two "
+                             f"dimensions: dimensions {self.width}x{self.height}")
+        levels = [self.pixels]
+        size = self.width
+        while size > 1:
+            src = levels[-1].astype(np.float32) / np.float32(255.0)
+            lin = src.copy()
+            lin[..., :3] = src[..., :3] * src[..., :3]                      # powi(2)
+            quad = [lin[0::2, 0::2], lin[0::2, 1::2], lin[1::2, 0::2], lin[1::2, 1::2]]
+            total = np.zeros_like(quad[0])
+            for q in quad:                                                   # sum in the reference's order
+                total = total + q
+            avg = total / np.float32(4.0)
+            out = avg.copy()
+            out[..., :3] = np.sqrt(avg[..., :3])                             # powf(1/2)
+            levels.append((out * np.float32(255.0)).astype(np.uint8))        # `as u8` truncates
+            size //= 2
+        self.level_count = len(levels)
+        self.mips = np.concatenate([lv.reshape(-1) for lv in levels])
+        return self
+
+    @property
+    def data(self):
+        return self.mips if self.mips is not None else self.pixels.reshape(-1)
+
+    @property
+    def mip_level_count(self):
+        return self.level_count if self.mips is not None else 1
+
+
+@dataclass
 class Material:
     """src/material.rs:3-19"""
     base_color: Color = Color.WHITE

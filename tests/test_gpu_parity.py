@@ -220,3 +220,40 @@ def test_directional_shadow_cascades():
     ids, hdr = cpu.read_triangle_ids(), cpu.read_color_hdr()
     floor = hdr[ids < 2].sum(axis=-1)
     assert (floor < 0.3 * np.median(floor)).sum() == 0
+
+
+def test_textured_materials_trilinear():
+    """N2: a lit height-field and a tilted quad, both textured with a 256^2 mip-mapped image (Repeat
+    addressing: the grid's uv run over many periods), seen in perspective so lambda varies."""
+    from renderer_amd.types import Image, Material
+    s = c2_grid_1m(width=400, height=240, scale=0.12)
+    r = np.random.default_rng(21)
+    px = r.integers(0, 256, (256, 256, 4)).astype(np.uint8)
+    yy, xx = np.mgrid[0:256, 0:256]
+    px[..., 0] = np.where(((xx // 32) + (yy // 32)) % 2 == 0, 230, 40)      # checker + noise in g, b
+    px[..., 3] = 255
+    image = Image(256, 256, px).make_mips()
+    pair = []
+    for make in (lambda: VisualServer(s.width, s.height, device=0), lambda: oracle_server(s.width, s.height)):
+        vs = make()
+        tex = vs.asset_server.add(image)
+        mat = vs.asset_server.add(Material(base_color=Color(0.9, 1.0, 0.8, 1.0), base_color_image=tex))
+        for m in s.meshes:
+            for sub in m.submeshes:
+                sub.material = mat
+        quad = Mesh.quad()
+        quad.submeshes[0].material = mat
+        handles = s.populate(vs)
+        qh = vs.asset_server.add(quad)
+        vs.set_mesh_instance(900, from_translation((0.5, 0.2, 2.0)) @ from_rotation_y(1.1) @ from_scale((3, 2, 1)), qh)
+        vs.render()
+        pair.append(vs)
+    gpu, cpu = pair
+    # integer planes bit-exact, 8-bit colour within 1 LSB everywhere; in HDR the f32 (here) vs f64 (oracle)
+    # uv and footprint move the filter weights in their last bits: a few f16 ulps, continuous
+    assert_parity(gpu, cpu, min_covered=400 * 240 // 2, hdr=False)
+    h_g, h_c = gpu.read_color_hdr(), cpu.read_color_hdr()
+    assert (np.abs(h_g - h_c) / np.maximum(np.abs(h_c), 1e-3)).max() <= 2 ** -8
+    # the texture is really there: the red channel shows both checker levels
+    red = cpu.read_color_hdr()[..., 0][cpu.read_coverage() == 1]
+    assert red.max() > 4 * max(red.min(), 1e-4)

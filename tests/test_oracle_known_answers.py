@@ -383,3 +383,70 @@ def test_ka12_directional_shadow_cascades():
     ids, hdr = cpu.read_triangle_ids(), cpu.read_color_hdr()
     floor = hdr[ids < 2].sum(axis=-1)
     assert (floor < 0.3 * np.median(floor)).sum() == 0
+
+
+# ---- KA13/KA14: textured materials ---------------------------------------
+
+def textured_quad_scene(vs, cam, size, image, w, h):
+    """A quad that covers the whole w x h frame with uv (0,0) at the top-left pixel corner."""
+    from renderer_amd.types import Image  # noqa: F401
+    tex = vs.asset_server.add(image)
+    mat = vs.asset_server.add(Material(base_color=Color(1, 1, 1, 1), base_color_image=tex, unlit=True))
+    corners = [(0, 0), (w, 0), (0, h), (w, h)]
+    pos = [screen_to_view(px, py, 2.0, w, h, cam) for px, py in corners]
+    uvs = [(0, 0), (1, 0), (0, 1), (1, 1)]
+    v = make_vertices(pos, uvs=uvs)
+    mesh = vs.asset_server.add(Mesh([Submesh(v, np.array([0, 2, 1, 1, 2, 3], dtype=np.uint32), mat)]))
+    vs.set_mesh_instance(1, identity(), mesh)
+
+
+def test_ka13_texture_one_texel_per_pixel_round_trips():
+    """Rgba8UnormSrgb texel -> linear -> unlit, no tone map -> sRGB surface: with one texel per pixel
+    (lambda = 0, taps on texel centres) the frame equals the texture bytes."""
+    from renderer_amd.types import Image
+    n = 16
+    r = np.random.default_rng(3)
+    px = r.integers(0, 256, (n, n, 4)).astype(np.uint8)
+    px[..., 3] = 255
+    cam = Camera(aspect_ratio=1.0)
+    vs = oracle_server(n, n, threads=1)
+    vs.set_tone_mapping(0)
+    vs.set_camera(identity(), cam)
+    textured_quad_scene(vs, cam, n, Image(n, n, px), n, n)
+    vs.render()
+    out = vs.read_color_rgba8()
+    assert (vs.read_coverage() == 1).all()
+    assert np.abs(out.astype(int) - px.astype(int)).max() <= 1
+    assert (out == px).mean() > 0.98
+
+
+def test_ka14_texture_minified_eightfold_reads_mip_3():
+    """A 128^2 texture on a 16^2 frame: rho = 8 texels per pixel, lambda = 3, and pixel centres fall on
+    the texel centres of level 3 — the frame equals the chain's fourth level (image.rs:34-186)."""
+    from renderer_amd.types import Image
+    n, frame = 128, 16
+    r = np.random.default_rng(4)
+    px = r.integers(0, 256, (n, n, 4)).astype(np.uint8)
+    px[..., 3] = 255
+    img = Image(n, n, px).make_mips()
+    assert img.mip_level_count == 8
+    off = sum((n >> l) ** 2 * 4 for l in range(3))
+    level3 = img.data[off:off + frame * frame * 4].reshape(frame, frame, 4)
+    cam = Camera(aspect_ratio=1.0)
+    vs = oracle_server(frame, frame, threads=1)
+    vs.set_tone_mapping(0)
+    vs.set_camera(identity(), cam)
+    textured_quad_scene(vs, cam, n, img, frame, frame)
+    vs.render()
+    out = vs.read_color_rgba8()
+    assert np.abs(out.astype(int) - level3.astype(int)).max() <= 1
+
+
+def test_ka15_texture_with_alpha_is_refused():
+    from renderer_amd import RndError
+    from renderer_amd.types import Image
+    px = np.full((4, 4, 4), 200, dtype=np.uint8)
+    vs = oracle_server(8, 8, threads=1)
+    tex = vs.asset_server.add(Image(4, 4, px))
+    with pytest.raises(RndError):
+        vs._register_texture(tex)
