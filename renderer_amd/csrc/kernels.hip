@@ -439,6 +439,68 @@ __device__ __forceinline__ void setup_triangle(const float4& c0, const float4& c
     if (ok0 && ok1 && ok2) emit = make_record(s0, s1, s2, gid, fc, rec, tr) && any_owned(tr, fc);
 }
 
+// Direct raster, wave-cooperative.  Per wave only a quarter of the triangles survive culling, and a
+// survivor covers a handful of pixel centres, so a per-lane pixel loop runs at the pace of the
+// largest bbox with most lanes idle.  Instead the survivors are compacted into LDS (rank by ballot)
+// and re-dealt four lanes per triangle: lane L of a pass takes triangle L/4 and its bbox pixels
+// L%4, L%4+4, ...; 16 triangles per pass.
+struct DirectTri {                  // 20 dwords = 5 x 16 B
+    int32_t r0, r1, r2;             // edge functions at the bbox's first pixel centre
+    int32_t sx0, sx1, sx2;          // ex * 256: step per pixel row
+    int32_t sy0, sy1, sy2;          // ey * 256: step per pixel column (subtracted)
+    uint32_t shape;                 // bbox width | pixel count << 8 | top-left bias bits << 16
+    float z0, dz1, dz2, inv_area;
+    uint32_t id;
+    uint32_t origin;                // i0 | j0 << 16
+    float inv_w;                    // 1 / bbox width
+    uint32_t pad[3];
+};
+static_assert(sizeof(DirectTri) == 80, "DirectTri is 5 x 16 bytes");
+
+__device__ __forceinline__ DirectTri make_direct(const SetupRecord& r, const TileRect& t) {
+    // same integers as raster_small (bbox below 64 px: every factor fits 24 bits)
+    const int32_t ex0 = r.x1 - r.x2, ey0 = r.y1 - r.y2;
+    const int32_t ex1 = r.x2 - r.x0, ey1 = r.y2 - r.y0;
+    const int32_t ex2 = r.x0 - r.x1, ey2 = r.y0 - r.y1;
+    const uint32_t b0 = ((-ey0 > 0) || (ey0 == 0 && ex0 > 0)) ? 0u : 1u;
+    const uint32_t b1 = ((-ey1 > 0) || (ey1 == 0 && ex1 > 0)) ? 0u : 1u;
+    const uint32_t b2 = ((-ey2 > 0) || (ey2 == 0 && ex2 > 0)) ? 0u : 1u;
+    const int32_t px = t.i0 * kSub + kSub / 2, py = t.j0 * kSub + kSub / 2;
+    DirectTri d;
+    d.r0 = __mul24(ex0, py - r.y2) - __mul24(ey0, px - r.x2);
+    d.r1 = __mul24(ex1, py - r.y0) - __mul24(ey1, px - r.x0);
+    d.r2 = __mul24(ex2, py - r.y1) - __mul24(ey2, px - r.x1);
+    d.sx0 = ex0 * kSub; d.sx1 = ex1 * kSub; d.sx2 = ex2 * kSub;
+    d.sy0 = ey0 * kSub; d.sy1 = ey1 * kSub; d.sy2 = ey2 * kSub;
+    const uint32_t w = (uint32_t)(t.i1 - t.i0 + 1), h = (uint32_t)(t.j1 - t.j0 + 1);
+    d.shape = w | ((w * h) << 8) | (b0 << 16) | (b1 << 17) | (b2 << 18);
+    d.z0 = r.z0; d.dz1 = r.dz1; d.dz2 = r.dz2; d.inv_area = r.inv_area;
+    d.id = r.tri_id;
+    d.origin = (uint32_t)t.i0 | ((uint32_t)t.j0 << 16);
+    d.inv_w = __builtin_amdgcn_rcpf((float)w);
+    d.pad[0] = d.pad[1] = d.pad[2] = 0;
+    return d;
+}
+
+// pixel k (row-major in the bbox) of a compacted triangle
+template <class Sink>
+__device__ __forceinline__ void direct_pixel(const DirectTri& d, uint32_t k, const Sink& sink) {
+    const uint32_t w = d.shape & 255u;
+    // k / w for k < 16, w <= 16: (k + 0.5) / w is at least 1/32 away from an integer, far beyond the
+    // 1 ulp of the approximate reciprocal
+    const uint32_t dj = (uint32_t)(((float)k + 0.5f) * d.inv_w);
+    const uint32_t di = k - dj * w;
+    const int32_t w0 = d.r0 + __mul24((int32_t)dj, d.sx0) - __mul24((int32_t)di, d.sy0);
+    const int32_t w1 = d.r1 + __mul24((int32_t)dj, d.sx1) - __mul24((int32_t)di, d.sy1);
+    const int32_t w2 = d.r2 + __mul24((int32_t)dj, d.sx2) - __mul24((int32_t)di, d.sy2);
+    const int32_t b0 = (int32_t)((d.shape >> 16) & 1u), b1 = (int32_t)((d.shape >> 17) & 1u), b2 = (int32_t)((d.shape >> 18) & 1u);
+    if (w0 >= b0 && w1 >= b1 && w2 >= b2) {
+        const float l1 = (float)w1 * d.inv_area, l2 = (float)w2 * d.inv_area;
+        const float z = (l1 * d.dz1 + l2 * d.dz2) + d.z0;
+        sink((int32_t)((d.origin & 0xFFFFu) + di), (int32_t)((d.origin >> 16) + dj), z, d.id);
+    }
+}
+
 // A triangle whose bbox holds at most kSmallPixels pixel centres (the bulk at C2..C5 density) is
 // rasterized right here by its lane, straight into the visibility buffer (GlobalSink); only the
 // larger ones become records and go through the bins to the per-tile raster kernel.
@@ -453,6 +515,7 @@ constexpr uint32_t kSetupChunk = kChunkTris;
 __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, FrameConst fc, Capacities cap) {
     __shared__ uint32_t s_used;         // record slots of this workgroup's chunk handed out so far
     __shared__ uint32_t s_valid[4];
+    __shared__ uint4 s_direct[4][64][5];   // per wave: the compacted small triangles of one iteration
     if (blockIdx.x >= fb.counters->n_active) return;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     const uint2 unit = fb.active_units[blockIdx.x];
@@ -503,10 +566,36 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, FrameConst fc, C
         }
         valid += (uint32_t)__popcll(__ballot(emit));
         // small triangles: rasterize now, no record
-        if (emit && (rec.flags & 1u) &&
-            (uint32_t)(tr.i1 - tr.i0 + 1) * (uint32_t)(tr.j1 - tr.j0 + 1) <= kSmallPixels) {
-            raster_small(rec, tr.i0, tr.i1, tr.j0, tr.j1, direct_sink);
-            emit = false;
+        const bool direct = emit && (rec.flags & 1u) &&
+                            (uint32_t)(tr.i1 - tr.i0 + 1) * (uint32_t)(tr.j1 - tr.j0 + 1) <= kSmallPixels;
+        const unsigned long long dm = __ballot(direct);
+        if (dm) {
+            if (direct) {
+                const DirectTri dt = make_direct(rec, tr);
+                const uint4* src = reinterpret_cast<const uint4*>(&dt);
+                uint4* dst = s_direct[wave][__popcll(dm & ((1ull << lane) - 1ull))];
+                dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3]; dst[4] = src[4];
+                emit = false;
+            }
+            // the wave's own LDS traffic is ordered by the hardware; keep the compiler from moving the
+            // reads above the writes (and the next iteration's writes above these reads)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t n_direct = (uint32_t)__popcll(dm);
+            for (uint32_t base = 0; base < n_direct; base += 16u) {
+                const uint32_t which = base + (lane >> 2);
+                if (which < n_direct) {
+                    DirectTri dt;
+                    uint4* dst = reinterpret_cast<uint4*>(&dt);
+                    const uint4* src = s_direct[wave][which];
+                    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3]; dst[4] = src[4];
+                    const uint32_t npix = (dt.shape >> 8) & 255u;
+                    for (uint32_t k = lane & 3u; k < npix; k += 4u) direct_pixel(dt, k, direct_sink);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
         // the rest become records: the wave takes its slots from the workgroup's chunk with one LDS
         // atomic (the waves of a workgroup do not wait for each other)
