@@ -716,52 +716,51 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(FrameBuffers fb, FrameConst
 #pragma unroll
         for (uint32_t k = 0; k < 8; ++k) v += part[k];
     }
-    // one pass: every thread owns a run of consecutive tiles (kept in registers when short), sums
-    // it, the sums are scanned over the workgroup, and the thread writes the offsets of its run
-    constexpr uint32_t kKeep = 8;
-    const uint32_t per = (n_tiles + 1023u) / 1024u;
-    const uint32_t first = tid * per, last = min(first + per, n_tiles);
-    uint32_t cnt[kKeep];
-    uint32_t sum = 0;
-    if (per <= kKeep) {
+    // Tiles go through LDS in batches of 8192 so that global traffic is coalesced (this is a single
+    // workgroup on one CU: with a strided pattern its one texture pipe was the whole kernel time).
+    // Per batch: coalesced load of count sums into LDS, every thread scans its run of 8 consecutive
+    // tiles, offsets go back through LDS and out coalesced.
+    constexpr uint32_t kBatch = 8192, kRun = kBatch / 1024;
+    __shared__ uint32_t s_tiles[kBatch + kBatch / 32];          // padded: a run of 8 starts in its own bank group
+    __shared__ uint32_t s_batch_total;
+    uint32_t carry = 0;
+    for (uint32_t batch = 0; batch < n_tiles; batch += kBatch) {
 #pragma unroll
-        for (uint32_t k = 0; k < kKeep; ++k) {
-            const uint32_t i = first + k;
-            cnt[k] = (k < per && i < n_tiles) ? fb.tile_count[i] + fb.tile_count[n_tiles + i] : 0u;
+        for (uint32_t k = 0; k < kRun; ++k) {
+            const uint32_t local = k * 1024u + tid, i = batch + local;
+            s_tiles[local + local / 32u] = i < n_tiles ? fb.tile_count[i] + fb.tile_count[n_tiles + i] : 0u;
         }
+        __syncthreads();
+        uint32_t cnt[kRun], sum = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < kKeep; ++k) sum += cnt[k];
-    } else {
-        for (uint32_t i = first; i < last; ++i) sum += fb.tile_count[i] + fb.tile_count[n_tiles + i];
-    }
-    uint32_t inc = sum;
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t up = __shfl_up(inc, o);
-        if (lane >= (uint32_t)o) inc += up;
+        for (uint32_t k = 0; k < kRun; ++k) { const uint32_t local = tid * kRun + k; cnt[k] = s_tiles[local + local / 32u]; sum += cnt[k]; }
+        uint32_t inc = sum;
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t up = __shfl_up(inc, o);
+            if (lane >= (uint32_t)o) inc += up;
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (uint32_t w = 0; w < wave; ++w) wave_off += s_wave[w];
+        uint32_t run = carry + wave_off + inc - sum;
+#pragma unroll
+        for (uint32_t k = 0; k < kRun; ++k) { const uint32_t local = tid * kRun + k; s_tiles[local + local / 32u] = run; run += cnt[k]; }
+        if (tid == 1023) s_batch_total = run;
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < kRun; ++k) {
+            const uint32_t local = k * 1024u + tid, i = batch + local;
+            if (i < n_tiles) { fb.tile_offset[i] = s_tiles[local + local / 32u]; fb.tile_cursor[i] = 0; }
+        }
+        carry = s_batch_total;
+        __syncthreads();
     }
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if (lane == 63) s_wave[wave] = inc;
     if (lane == 0) s_valid[wave] = v;
     __syncthreads();
-    uint32_t wave_off = 0;
-    for (uint32_t w = 0; w < wave; ++w) wave_off += s_wave[w];
-    uint32_t run = wave_off + inc - sum;
-    if (per <= kKeep) {
-#pragma unroll
-        for (uint32_t k = 0; k < kKeep; ++k) {
-            const uint32_t i = first + k;
-            if (k < per && i < n_tiles) { fb.tile_offset[i] = run; fb.tile_cursor[i] = 0; }
-            run += cnt[k];
-        }
-    } else {
-        for (uint32_t i = first; i < last; ++i) {
-            fb.tile_offset[i] = run;
-            fb.tile_cursor[i] = 0;
-            run += fb.tile_count[i] + fb.tile_count[n_tiles + i];
-        }
-    }
     if (tid == 1023) {
-        const uint32_t n_entries = wave_off + inc;
+        const uint32_t n_entries = carry;
         uint32_t total = 0;
         for (uint32_t w = 0; w < 16; ++w) total += s_valid[w];
         atomicAdd(&fb.counters->n_valid, total);
