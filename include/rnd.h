@@ -111,6 +111,12 @@ int rnd_render_size(const rnd_ctx* ctx, uint32_t* width, uint32_t* height);  /* 
 int rnd_set_render_size(rnd_ctx* ctx, uint32_t width, uint32_t height);      /* :160 */
 int rnd_render_size_factor(const rnd_ctx* ctx, float* factor);               /* :165 */
 int rnd_set_render_size_factor(rnd_ctx* ctx, float factor);                  /* :169 */
+/* Resolution of the 3D render target: render_size * render_size_factor, truncated
+ * (recreate_render_targets :621-623).  rnd_read_depth / _coverage / _triangle_ids / _color_hdr
+ * return planes of this size; rnd_read_color_rgba8 returns the presented frame at render_size
+ * (show_texture.wgsl over the surface: nearest sampler at factors <= 1, linear above, :629-633).
+ * No counterpart in the reference (its tests read nothing back). */
+int rnd_render_resolution(const rnd_ctx* ctx, uint32_t* width, uint32_t* height);
 int rnd_msaa_sample_count(const rnd_ctx* ctx, uint32_t* count);              /* :174 */
 int rnd_set_msaa(rnd_ctx* ctx, uint32_t sample_count);                       /* :178 */
 int rnd_tone_mapping(const rnd_ctx* ctx, uint32_t* mode);                    /* :183 */

@@ -265,7 +265,8 @@ static inline void barycentrics(const V4& c0, const V4& c1, const V4& c2, uint32
 
 // ------------------------------------------------------------------------------------
 struct Ctx {
-    uint32_t W = 0, H = 0;
+    uint32_t W = 0, H = 0;             // resolution of the 3D render target: surface size * size_factor, truncated (visual_server.rs:621-623)
+    uint32_t SW = 0, SH = 0;           // surface (render_size)
     float size_factor = 1.0f;
     uint32_t msaa = 1;
     uint32_t tone = RND_TONE_MAPPING_REINHARD;
@@ -800,9 +801,40 @@ static int render(Ctx& c) {
             }
         }
     }
-    parallel_for(c.threads, P, [&](size_t lo, size_t hi) {
-        for (size_t p = lo; p < hi; ++p) present_pixel(c, &c.hdr[p * 3], &c.rgba[p * 4]);
-    });
+    if (c.SW == W && c.SH == H) {
+        parallel_for(c.threads, P, [&](size_t lo, size_t hi) {
+            for (size_t p = lo; p < hi; ++p) present_pixel(c, &c.hdr[p * 3], &c.rgba[p * 4]);
+        });
+    } else {
+        // show_texture.wgsl over the surface: uv = pixel centre / surface size; the 3D target is sampled
+        // with the unfiltered sampler (nearest, ClampToEdge) at factors <= 1 and the filtered one
+        // (linear, Repeat; one mip level, isotropic) above 1 (visual_server.rs:629-633), then tone-mapped
+        c.rgba.assign((size_t)c.SW * c.SH * 4, 0);
+        const bool linear = c.size_factor > 1.0f;
+        parallel_for(c.threads, c.SH, [&](size_t lo, size_t hi) {
+            for (size_t j = lo; j < hi; ++j)
+                for (uint32_t i = 0; i < c.SW; ++i) {
+                    const float u = ((float)i + 0.5f) / (float)c.SW, v = ((float)j + 0.5f) / (float)c.SH;
+                    float px[3];
+                    if (!linear) {
+                        uint32_t x = std::min((uint32_t)std::floor(u * (float)W), W - 1), y = std::min((uint32_t)std::floor(v * (float)H), H - 1);
+                        for (int k = 0; k < 3; ++k) px[k] = c.hdr[((size_t)y * W + x) * 3 + k];
+                    } else {
+                        const float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+                        const float xf = std::floor(x), yf = std::floor(y), fx = x - xf, fy = y - yf;
+                        auto wrap = [](float f, uint32_t n) { long long k = (long long)f % (long long)n; return (uint32_t)(k < 0 ? k + n : k); };
+                        const uint32_t x0 = wrap(xf, W), x1 = wrap(xf + 1.0f, W), y0 = wrap(yf, H), y1 = wrap(yf + 1.0f, H);
+                        for (int k = 0; k < 3; ++k) {
+                            const float t00 = c.hdr[((size_t)y0 * W + x0) * 3 + k], t10 = c.hdr[((size_t)y0 * W + x1) * 3 + k];
+                            const float t01 = c.hdr[((size_t)y1 * W + x0) * 3 + k], t11 = c.hdr[((size_t)y1 * W + x1) * 3 + k];
+                            const float top = t00 * (1.0f - fx) + t10 * fx, bot = t01 * (1.0f - fx) + t11 * fx;
+                            px[k] = top * (1.0f - fy) + bot * fy;
+                        }
+                    }
+                    present_pixel(c, px, &c.rgba[((size_t)j * c.SW + i) * 4]);
+                }
+        });
+    }
 
     auto t_end = std::chrono::steady_clock::now();
     c.timings = rnd_timings{};
@@ -834,7 +866,7 @@ int orc_create(rnd_ctx** out, uint32_t width, uint32_t height, int /*device*/) {
         return RND_ERR_INVALID;
     }
     Ctx* c = new Ctx();
-    c->W = width; c->H = height;
+    c->W = c->SW = width; c->H = c->SH = height;
     c->meshes[orc::QUAD_MESH_ID] = orc::quad_mesh();
     *out = reinterpret_cast<rnd_ctx*>(c);
     return RND_OK;
@@ -843,16 +875,20 @@ void orc_destroy(rnd_ctx* ctx) { delete CTX(ctx); }
 const char* orc_last_error(const rnd_ctx* ctx) { return ctx ? CCTX(ctx)->err.c_str() : g_create_err.c_str(); }
 const char* orc_backend_name(void) { return "cpu-oracle"; }
 
-int orc_render_size(const rnd_ctx* ctx, uint32_t* w, uint32_t* h) { *w = CCTX(ctx)->W; *h = CCTX(ctx)->H; return RND_OK; }
-int orc_set_render_size(rnd_ctx* ctx, uint32_t w, uint32_t h) {
-    if (w == 0 || h == 0 || w > 16384 || h > 16384) { CTX(ctx)->err = "bad size"; return RND_ERR_INVALID; }
-    CTX(ctx)->W = w; CTX(ctx)->H = h; CTX(ctx)->have_frame = false; return RND_OK;
-}
-int orc_render_size_factor(const rnd_ctx* ctx, float* f) { *f = CCTX(ctx)->size_factor; return RND_OK; }
-int orc_set_render_size_factor(rnd_ctx* ctx, float f) {
-    if (f != 1.0f) { CTX(ctx)->err = "render_size_factor != 1 not built yet (SURVEY §8f N4)"; return RND_ERR_UNSUPPORTED; }
+int orc_render_size(const rnd_ctx* ctx, uint32_t* w, uint32_t* h) { *w = CCTX(ctx)->SW; *h = CCTX(ctx)->SH; return RND_OK; }
+int orc_render_resolution(const rnd_ctx* ctx, uint32_t* w, uint32_t* h) { *w = CCTX(ctx)->W; *h = CCTX(ctx)->H; return RND_OK; }
+static int orc_apply_size(Ctx* c, uint32_t sw, uint32_t sh, float f) {
+    // recreate_render_targets (visual_server.rs:621-623): (render_size.as_vec2() * factor).as_uvec2()
+    if (!(f > 0.0f) || !(f <= 16.0f)) { c->err = "render_size_factor must be in (0, 16]"; return RND_ERR_INVALID; }
+    const uint32_t w = (uint32_t)((float)sw * f), h = (uint32_t)((float)sh * f);
+    if (sw == 0 || sh == 0 || w == 0 || h == 0 || w > 16384 || h > 16384) { c->err = "bad size"; return RND_ERR_INVALID; }
+    if (f != 1.0f && c->world > 1) { c->err = "render_size_factor != 1 on a tile partition is not built"; return RND_ERR_UNSUPPORTED; }
+    c->SW = sw; c->SH = sh; c->W = w; c->H = h; c->size_factor = f; c->have_frame = false;
     return RND_OK;
 }
+int orc_set_render_size(rnd_ctx* ctx, uint32_t w, uint32_t h) { return orc_apply_size(CTX(ctx), w, h, CCTX(ctx)->size_factor); }
+int orc_render_size_factor(const rnd_ctx* ctx, float* f) { *f = CCTX(ctx)->size_factor; return RND_OK; }
+int orc_set_render_size_factor(rnd_ctx* ctx, float f) { return orc_apply_size(CTX(ctx), CCTX(ctx)->SW, CCTX(ctx)->SH, f); }
 int orc_msaa_sample_count(const rnd_ctx* ctx, uint32_t* n) { *n = CCTX(ctx)->msaa; return RND_OK; }
 int orc_set_msaa(rnd_ctx* ctx, uint32_t n) {
     if (n != 1) { CTX(ctx)->err = "MSAA != 1 not built yet (SURVEY §8f N4)"; return n == 4 ? RND_ERR_UNSUPPORTED : RND_ERR_INVALID; }
@@ -997,6 +1033,7 @@ int orc_frame_stats_get(rnd_ctx* ctx, rnd_frame_stats* out) { *out = CTX(ctx)->s
 int orc_set_tile_partition(rnd_ctx* ctx, uint32_t rank, uint32_t world) {
     Ctx* c = CTX(ctx);
     if (world == 0 || rank >= world) { c->err = "bad partition"; return RND_ERR_INVALID; }
+    if (world > 1 && c->size_factor != 1.0f) { c->err = "render_size_factor != 1 on a tile partition is not built"; return RND_ERR_UNSUPPORTED; }
     c->rank = rank; c->world = world; return RND_OK;
 }
 int orc_tile_info(const rnd_ctx* ctx, uint32_t* tile_px, uint32_t* n_owned, uint32_t* n_total) {

@@ -72,6 +72,7 @@ SIGNATURES = {
     "backend_name": (C.c_char_p, []),
     "render_size": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "set_render_size": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "render_resolution": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "render_size_factor": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "set_render_size_factor": (C.c_int, [_P, C.c_float]),
     "msaa_sample_count": (C.c_int, [_P, C.POINTER(C.c_uint32)]),

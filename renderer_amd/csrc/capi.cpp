@@ -73,6 +73,10 @@ int rnd_render_size(const rnd_ctx* ctx, uint32_t* w, uint32_t* h) {
     REQUIRE(const_cast<rnd_ctx*>(ctx), w && h, "null output");
     return guard(ctx, [&](rnd::VisualServer& v) { v.render_size(*w, *h); });
 }
+int rnd_render_resolution(const rnd_ctx* ctx, uint32_t* w, uint32_t* h) {
+    REQUIRE(const_cast<rnd_ctx*>(ctx), w && h, "null output");
+    return guard(ctx, [&](rnd::VisualServer& v) { v.render_resolution(*w, *h); });
+}
 int rnd_set_render_size(rnd_ctx* ctx, uint32_t w, uint32_t h) { return guard(ctx, [&](rnd::VisualServer& v) { v.set_render_size(w, h); }); }
 int rnd_render_size_factor(const rnd_ctx* ctx, float* f) {
     REQUIRE(const_cast<rnd_ctx*>(ctx), f, "null output");

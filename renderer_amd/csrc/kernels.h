@@ -62,6 +62,11 @@ void launch_split_positions(const rnd_vertex* verts, uint32_t n, float* px, floa
 // tile-major RGBA8 of `n` tiles (list `tiles`) -> row-major frame
 void launch_detile(const uint8_t* tiles_rgba8, const uint32_t* tiles, uint32_t n, const FrameConst& fc,
                    uint8_t* frame_rgba8, hipStream_t stream);
+// show_texture.wgsl for a 3D target whose size differs from the surface (render_size_factor != 1):
+// hdr (w x h, rgb f32 holding f16 values) sampled at the surface's pixel centres, nearest or
+// linear, then tone map + sRGB into the sw x sh RGBA8 frame
+void launch_present(const float* hdr, uint32_t w, uint32_t h, uint8_t* frame_rgba8, uint32_t sw, uint32_t sh,
+                    bool linear, uint32_t tone, hipStream_t stream);
 // packed (depth | rgba8) row-major -> RGBA8 frame + tile-major vis depth
 void launch_unpack(const uint64_t* packed, const FrameConst& fc, uint8_t* frame_rgba8, float* depth,
                    hipStream_t stream);

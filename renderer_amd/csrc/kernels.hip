@@ -1467,6 +1467,37 @@ __global__ void k_detile(const uint32_t* __restrict__ tiles_rgba8, const uint32_
     }
 }
 
+__global__ void k_present(const float* __restrict__ hdr, uint32_t w, uint32_t h, uint32_t* __restrict__ frame,
+                          uint32_t sw, uint32_t sh, uint32_t linear, uint32_t tone) {
+    const uint32_t i = blockIdx.x * 64u + (threadIdx.x & 63u), j = blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (i >= sw || j >= sh) return;
+    const float u = ((float)i + 0.5f) / (float)sw, v = ((float)j + 0.5f) / (float)sh;
+    float c[3];
+    if (!linear) {          // unfiltered sampler: nearest, ClampToEdge (backend.rs:428-439)
+        const uint32_t x = min((uint32_t)floorf(u * (float)w), w - 1u), y = min((uint32_t)floorf(v * (float)h), h - 1u);
+        const float* p = hdr + ((size_t)y * w + x) * 3;
+        c[0] = p[0]; c[1] = p[1]; c[2] = p[2];
+    } else {                // filtered sampler: linear, Repeat (backend.rs:414-426); one level, isotropic
+        const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+        const float xf = floorf(x), yf = floorf(y), fx = x - xf, fy = y - yf;
+        auto wrap = [](float f, uint32_t n) { long long k = (long long)f % (long long)n; return (uint32_t)(k < 0 ? k + (long long)n : k); };
+        const uint32_t x0 = wrap(xf, w), x1 = wrap(xf + 1.0f, w), y0 = wrap(yf, h), y1 = wrap(yf + 1.0f, h);
+        const float* p00 = hdr + ((size_t)y0 * w + x0) * 3, *p10 = hdr + ((size_t)y0 * w + x1) * 3;
+        const float* p01 = hdr + ((size_t)y1 * w + x0) * 3, *p11 = hdr + ((size_t)y1 * w + x1) * 3;
+        for (int k = 0; k < 3; ++k) {
+            const float top = p00[k] * (1.0f - fx) + p10[k] * fx, bot = p01[k] * (1.0f - fx) + p11[k] * fx;
+            c[k] = top * (1.0f - fy) + bot * fy;
+        }
+    }
+    float r = c[0], g = c[1], b = c[2];
+    if (tone == RND_TONE_MAPPING_REINHARD) {
+        const float lum = (0.2126f * r + 0.7152f * g) + 0.0722f * b;
+        const float dd = lum + 1.0f;
+        r = r / dd; g = g / dd; b = b / dd;
+    }
+    frame[(size_t)j * sw + i] = srgb8(r) | (srgb8(g) << 8) | (srgb8(b) << 16) | 0xFF000000u;
+}
+
 __global__ void k_unpack(const unsigned long long* __restrict__ packed, FrameConst fc, uint32_t* frame, float* depth) {
     size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= (size_t)fc.width * fc.height) return;
@@ -1544,6 +1575,11 @@ void launch_detile(const uint8_t* tiles_rgba8, const uint32_t* tiles, uint32_t n
     if (!n) return;
     hipLaunchKernelGGL(k_detile, dim3(n), dim3(256), 0, stream, reinterpret_cast<const uint32_t*>(tiles_rgba8), tiles,
                        fc, reinterpret_cast<uint32_t*>(frame_rgba8));
+}
+void launch_present(const float* hdr, uint32_t w, uint32_t h, uint8_t* frame_rgba8, uint32_t sw, uint32_t sh,
+                    bool linear, uint32_t tone, hipStream_t stream) {
+    hipLaunchKernelGGL(k_present, dim3(div_up(sw, 64), div_up(sh, 4)), dim3(256), 0, stream, hdr, w, h,
+                       reinterpret_cast<uint32_t*>(frame_rgba8), sw, sh, linear ? 1u : 0u, tone);
 }
 void launch_unpack(const uint64_t* packed, const FrameConst& fc, uint8_t* frame_rgba8, float* depth, hipStream_t stream) {
     size_t n = (size_t)fc.width * fc.height;

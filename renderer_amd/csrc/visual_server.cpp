@@ -45,6 +45,7 @@ VisualServer::VisualServer(uint32_t width, uint32_t height, int device) : device
     int n_dev = 0;
     HIP_CHECK(hipGetDeviceCount(&n_dev));
     if (device < 0 || device >= n_dev) throw Error(RND_ERR_INVALID, "no such HIP device");
+    surface_w_ = width; surface_h_ = height;
     use_device();
     HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     for (auto& es : event_sets_)
@@ -94,18 +95,23 @@ VisualServer::~VisualServer() {
 void VisualServer::use_device() const { HIP_CHECK(hipSetDevice(device_)); }
 
 // ---- settings ------------------------------------------------------------------------------
-void VisualServer::set_render_size(uint32_t w, uint32_t h) {
-    if (w == 0 || h == 0 || w > kMaxRenderSize || h > kMaxRenderSize) throw Error(RND_ERR_INVALID, "render size must be in 1..8192");
+// recreate_render_targets — visual_server.rs:621-662: the 3D target is
+// (render_size.as_vec2() * render_size_factor).as_uvec2()
+void VisualServer::apply_size(uint32_t sw, uint32_t sh, float f) {
+    if (!(f > 0.0f) || !(f <= 16.0f)) throw Error(RND_ERR_INVALID, "render_size_factor must be in (0, 16]");
+    if (sw == 0 || sh == 0 || sw > kMaxRenderSize || sh > kMaxRenderSize) throw Error(RND_ERR_INVALID, "render size must be in 1..8192");
+    const uint32_t w = (uint32_t)((float)sw * f), h = (uint32_t)((float)sh * f);
+    if (w == 0 || h == 0 || w > kMaxRenderSize || h > kMaxRenderSize) throw Error(RND_ERR_INVALID, "render size * factor must be in 1..8192");
+    if (f != 1.0f && world_ > 1) throw Error(RND_ERR_UNSUPPORTED, "render_size_factor != 1 on a tile partition is not built");
     finish();
-    width_ = w; height_ = h;
+    surface_w_ = sw; surface_h_ = sh; width_ = w; height_ = h; render_size_factor_ = f;
     ext_tiles_ = nullptr; ext_tiles_bytes_ = 0;
     have_frame_ = false;
-    rebuild_tiles();   // recreate_render_targets — visual_server.rs:621-662
+    rebuild_tiles();
+    if (scaled()) { use_device(); d_present_.ensure((size_t)surface_w_ * surface_h_ * 4); }
 }
-void VisualServer::set_render_size_factor(float f) {
-    if (f != 1.0f) throw Error(RND_ERR_UNSUPPORTED, "render_size_factor != 1 not built yet (SURVEY §8f N4)");
-    render_size_factor_ = f;
-}
+void VisualServer::set_render_size(uint32_t w, uint32_t h) { apply_size(w, h, render_size_factor_); }
+void VisualServer::set_render_size_factor(float f) { apply_size(surface_w_, surface_h_, f); }
 void VisualServer::set_msaa(uint32_t n) {
     if (n == 1) { msaa_ = 1; return; }
     if (n == 4) throw Error(RND_ERR_UNSUPPORTED, "MSAA 4 not built yet (SURVEY §8f N4)");
@@ -151,6 +157,7 @@ void VisualServer::rebuild_tiles() {
 
 void VisualServer::set_tile_partition(uint32_t rank, uint32_t world) {
     if (world == 0 || rank >= world) throw Error(RND_ERR_INVALID, "rank must be < world");
+    if (world > 1 && scaled()) throw Error(RND_ERR_UNSUPPORTED, "render_size_factor != 1 on a tile partition is not built");
     finish();
     rank_ = rank; world_ = world;
     ext_tiles_ = nullptr; ext_tiles_bytes_ = 0;
@@ -423,6 +430,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 void VisualServer::enqueue_frame(bool want_hdr) {
     use_device();
+    if (scaled()) want_hdr = true;      // the present pass samples the HDR target
     std::vector<DrawItem> items;
     std::vector<uint32_t> vert_bases, tri_bases, unit_bases;
     std::vector<GpuLight> lights;
@@ -540,7 +548,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     fb.entries = d_entries_.ptr; fb.counters = d_counters_.ptr;
     fb.launch_order = d_launch_order_.ptr; fb.n_owned = n_owned_;
     fb.vis = d_vis_.ptr;
-    fb.frame_rgba8 = world_ > 1 ? nullptr : d_frame_.ptr;
+    fb.frame_rgba8 = (world_ > 1 || scaled()) ? nullptr : d_frame_.ptr;
     fb.tiles_rgba8 = world_ > 1 ? (ext_tiles_ ? ext_tiles_ : d_tiles_.ptr) : nullptr;
     fb.packed = want_packed_ ? d_packed_.ptr : nullptr;
     fb.hdr = want_hdr ? d_hdr_.ptr : nullptr;
@@ -589,6 +597,8 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     launch_raster(fb, fc, cap_, stream_);
     HIP_CHECK(hipEventRecord(ev_[5], stream_));
     launch_shade(fb, fc, stream_);
+    if (scaled())   // show_texture.wgsl over the surface (visual_server.rs:629-633: filtered sampler above factor 1)
+        launch_present(d_hdr_.ptr, width_, height_, d_present_.ptr, surface_w_, surface_h_, render_size_factor_ > 1.0f, tone_mapping_, stream_);
     HIP_CHECK(hipEventRecord(ev_[6], stream_));
     es.pending = true;
     HIP_CHECK(hipMemcpyAsync(h_counters_, d_counters_.ptr, n_counter_sets_ * sizeof(FrameCounters), hipMemcpyDeviceToHost, stream_));
@@ -696,7 +706,8 @@ void VisualServer::read_color_rgba8(uint8_t* dst) {
         HIP_CHECK(hipMemsetAsync(d_frame_.ptr, 0, (size_t)width_ * height_ * 4, stream_));
         detile(rank_, world_, ext_tiles_ ? ext_tiles_ : d_tiles_.ptr);
     }
-    HIP_CHECK(hipMemcpyAsync(dst, d_frame_.ptr, (size_t)width_ * height_ * 4, hipMemcpyDeviceToHost, stream_));
+    if (scaled()) HIP_CHECK(hipMemcpyAsync(dst, d_present_.ptr, (size_t)surface_w_ * surface_h_ * 4, hipMemcpyDeviceToHost, stream_));
+    else HIP_CHECK(hipMemcpyAsync(dst, d_frame_.ptr, (size_t)width_ * height_ * 4, hipMemcpyDeviceToHost, stream_));
     HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
@@ -769,6 +780,7 @@ void VisualServer::detile(uint32_t src_rank, uint32_t world, const void* dev_til
 
 void VisualServer::packed_device_ptr(void** p, uint64_t* bytes) {
     use_device();
+    if (scaled()) throw Error(RND_ERR_UNSUPPORTED, "the packed (sort-last) frame is not built for render_size_factor != 1");
     if (!want_packed_ || !have_frame_) {
         want_packed_ = true;
         finish();
@@ -799,6 +811,7 @@ void VisualServer::set_stream(hipStream_t s) {
 }
 
 void VisualServer::color_device_ptr(void** p, uint64_t* bytes) {
+    if (scaled()) { *p = d_present_.ptr; *bytes = (uint64_t)surface_w_ * surface_h_ * 4; return; }
     *p = d_frame_.ptr; *bytes = (uint64_t)width_ * height_ * 4;
 }
 

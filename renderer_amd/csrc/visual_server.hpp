@@ -83,7 +83,8 @@ public:
     VisualServer(const VisualServer&) = delete;
 
     // settings — visual_server.rs:156-190
-    void render_size(uint32_t& w, uint32_t& h) const { w = width_; h = height_; }
+    void render_size(uint32_t& w, uint32_t& h) const { w = surface_w_; h = surface_h_; }
+    void render_resolution(uint32_t& w, uint32_t& h) const { w = width_; h = height_; }
     void set_render_size(uint32_t w, uint32_t h);
     float render_size_factor() const { return render_size_factor_; }
     void set_render_size_factor(float f);
@@ -143,7 +144,11 @@ private:
     void need_frame() const;
 
     int device_;
-    uint32_t width_, height_;
+    uint32_t width_, height_;            // the 3D render target: surface * render_size_factor, truncated
+    uint32_t surface_w_ = 0, surface_h_ = 0;
+    void apply_size(uint32_t sw, uint32_t sh, float factor);
+    bool scaled() const { return width_ != surface_w_ || height_ != surface_h_; }
+    DeviceBuffer<uint8_t> d_present_;     // surface-sized RGBA8 when scaled()
     float render_size_factor_ = 1.0f;
     uint32_t msaa_ = 1;
     uint32_t tone_mapping_ = RND_TONE_MAPPING_REINHARD;

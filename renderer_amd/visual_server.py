@@ -63,6 +63,12 @@ class VisualServer:
         self._check(self.api.render_size(self._ctx, C.byref(w), C.byref(h)))
         return (w.value, h.value)
 
+    def render_resolution(self):
+        """Size of the 3D render target: render_size * render_size_factor (visual_server.rs:621-623)."""
+        w, h = C.c_uint32(), C.c_uint32()
+        self._check(self.api.render_resolution(self._ctx, C.byref(w), C.byref(h)))
+        return (w.value, h.value)
+
     def set_render_size(self, size):
         self._check(self.api.set_render_size(self._ctx, int(size[0]), int(size[1])))
 
@@ -202,19 +208,19 @@ class VisualServer:
         return self._read(self.api.read_color_rgba8, (h, w, 4), np.uint8)
 
     def read_color_hdr(self):
-        w, h = self.render_size()
+        w, h = self.render_resolution()
         return self._read(self.api.read_color_hdr, (h, w, 3), np.float32)
 
     def read_depth(self):
-        w, h = self.render_size()
+        w, h = self.render_resolution()
         return self._read(self.api.read_depth, (h, w), np.float32)
 
     def read_coverage(self):
-        w, h = self.render_size()
+        w, h = self.render_resolution()
         return self._read(self.api.read_coverage, (h, w), np.uint8)
 
     def read_triangle_ids(self):
-        w, h = self.render_size()
+        w, h = self.render_resolution()
         return self._read(self.api.read_triangle_ids, (h, w), np.uint32)
 
     def last_timings(self):

@@ -52,7 +52,8 @@ def assert_parity(gpu, cpu, min_covered=1, hdr=True, shadow_taps=False):
     if hdr:
         h_g, h_c = gpu.read_color_hdr(), cpu.read_color_hdr()
         rel = np.abs(h_g - h_c) / np.maximum(np.abs(h_c), 1e-3)
-        rel = rel[~flips]
+        if rel.shape[:2] == flips.shape:      # (a scaled 3D target has its own resolution)
+            rel = rel[~flips]
         # the light loop uses v_rcp/v_rsq (1 ulp): the f32 sums differ in the last bits, which can move
         # a value across an f16 rounding boundary: at most one f16 ulp, on a small share of values
         assert rel.max() <= 2 ** -10, f"HDR differs, max rel {rel.max()}"
@@ -257,3 +258,27 @@ def test_textured_materials_trilinear():
     # the texture is really there: the red channel shows both checker levels
     red = cpu.read_color_hdr()[..., 0][cpu.read_coverage() == 1]
     assert red.max() > 4 * max(red.min(), 1e-4)
+
+
+@pytest.mark.parametrize("factor", [0.5, 2.0, 1.5])
+def test_render_size_factor(factor):
+    """N4: 3D target at render_size * factor, presented on the surface by show_texture.wgsl (nearest at
+    factors <= 1, linear above; tone map after the sampling)."""
+    s = soup_scene(31, 200, 120, n_meshes=3, n_tri=80, lights=3)
+    s.lights = [l for l in s.lights if l[2].kind_id() == 1]          # point lights only: strict tolerance
+    pair = []
+    for make in (lambda: VisualServer(s.width, s.height, device=0), lambda: oracle_server(s.width, s.height)):
+        vs = make()
+        vs.set_render_size_factor(factor)
+        s.populate(vs)
+        vs.render()
+        pair.append(vs)
+    gpu, cpu = pair
+    assert gpu.render_size() == (200, 120) and gpu.render_resolution() == (int(200 * factor), int(120 * factor))
+    assert gpu.read_color_rgba8().shape == (120, 200, 4)
+    assert_parity(gpu, cpu, min_covered=int(3000 * factor * factor))
+    # back to 1.0: the plain path again
+    for vs in pair:
+        vs.set_render_size_factor(1.0)
+        vs.render()
+    assert_parity(gpu, cpu, min_covered=3000)

@@ -450,3 +450,38 @@ def test_ka15_texture_with_alpha_is_refused():
     tex = vs.asset_server.add(Image(4, 4, px))
     with pytest.raises(RndError):
         vs._register_texture(tex)
+
+
+# ---- KA16: render_size_factor ----------------------------------------------
+
+@pytest.mark.parametrize("factor", [0.5, 0.25, 2.0])
+def test_ka16_render_size_factor(factor):
+    """The 3D target is render_size * factor (visual_server.rs:621-623) and is shown on the surface by
+    show_texture.wgsl: nearest at factors <= 1 (every surface pixel copies the target pixel under its
+    centre), linear above 1 (at factor 2 the centre falls on a corner shared by four target pixels:
+    their mean, taken in HDR before the tone map)."""
+    w, h = 64, 48
+    vs, cam = server(w=w, h=h)
+    vs.set_light(5, from_translation((0.3, 0.2, 0.5)), Light.point(6.0).with_color(Color(1.0, 0.8, 0.6, 2.0)))
+    screen_tri(vs, cam, [(4, 6), (10, 44), (60, 20)], z=2.0, w=w, h=h)
+    vs.set_render_size_factor(factor)
+    assert vs.render_size() == (w, h) and vs.render_resolution() == (int(w * factor), int(h * factor))
+    vs.render()
+    out, hdr = vs.read_color_rgba8(), vs.read_color_hdr()
+    assert out.shape == (h, w, 4) and hdr.shape == (int(h * factor), int(w * factor), 3)
+
+    def present(c):
+        c = c.astype(np.float64)
+        c = c / ((0.2126 * c[..., 0] + 0.7152 * c[..., 1] + 0.0722 * c[..., 2]) + 1.0)[..., None]
+        y = np.where(c <= 0.0031308, 12.92 * c, 1.055 * np.clip(c, 1e-12, None) ** (1 / 2.4) - 0.055)
+        return np.floor(np.clip(y, 0, 1) * 255.0 + 0.5).astype(int)
+
+    if factor <= 1:
+        k = int(round(1 / factor))
+        want = present(np.repeat(np.repeat(hdr, k, axis=0), k, axis=1))
+    else:
+        k = int(factor)
+        want = present(hdr.reshape(h, k, w, k, 3).astype(np.float64).mean(axis=(1, 3)))
+    assert np.abs(out[..., :3].astype(int) - want).max() <= 1
+    assert (out[..., 3] == 255).all()
+    assert (vs.read_coverage().sum() > 50 * factor * factor)
