@@ -73,6 +73,7 @@ extern "C" {
     pub fn rnd_set_render_size(ctx: *mut rnd_ctx, width: u32, height: u32) -> c_int;
     pub fn rnd_render_size_factor(ctx: *const rnd_ctx, factor: *mut f32) -> c_int;
     pub fn rnd_set_render_size_factor(ctx: *mut rnd_ctx, factor: f32) -> c_int;
+    pub fn rnd_render_resolution(ctx: *const rnd_ctx, width: *mut u32, height: *mut u32) -> c_int;
     pub fn rnd_msaa_sample_count(ctx: *const rnd_ctx, count: *mut u32) -> c_int;
     pub fn rnd_set_msaa(ctx: *mut rnd_ctx, sample_count: u32) -> c_int;
     pub fn rnd_tone_mapping(ctx: *const rnd_ctx, mode: *mut u32) -> c_int;
