@@ -134,8 +134,8 @@ int rnd_register_material(rnd_ctx* ctx, uint32_t material_id, const float base_c
 /* reference: register_texture/update_texture :752-769; data layout = Image::data(),
  * tightly packed RGBA8 mip levels, largest first, level l = max(1,w>>l) x max(1,h>>l)
  * (crates/asset_image/src/image.rs:34-113); sampled as Rgba8UnormSrgb (backend.rs:376) with
- * Repeat + trilinear (backend.rs:414-426).  Textures with any alpha below 255 return
- * RND_ERR_UNSUPPORTED for now (they need the per-fragment alpha test, render_mesh.wgsl:91). */
+ * Repeat + trilinear (backend.rs:414-426).  A texture with any alpha below 255 turns on the
+ * per-fragment alpha test (render_mesh.wgsl:89-92) for the draw items that use it. */
 int rnd_register_texture(rnd_ctx* ctx, uint32_t texture_id, uint32_t width, uint32_t height,
                          uint32_t mip_levels, const uint8_t* rgba8_mipchain);
 

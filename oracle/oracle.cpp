@@ -686,10 +686,16 @@ static int render(Ctx& c) {
     for (size_t k = 0; k < P; ++k) vis[k].store(CLEAR_KEY, std::memory_order_relaxed);
     for (const DrawItem& it : items) {
         float bc[4];
-        base_color(c, it.mat, nullptr, bc);     // textures are opaque (register_texture), so alpha is the material's
+        base_color(c, it.mat, nullptr, bc);     // texel alpha <= 1: below 0.5 here means below 0.5 for every fragment
         if (bc[3] < 0.5f) continue;
         const Submesh& s = *it.sub;
         size_t ntri = s.idx.size() / 3;
+        // textures with alpha: base.a < 0.5 is decided per fragment (render_mesh.wgsl:89-92)
+        const Texture* alpha_tex = nullptr;
+        if (it.mat.texture != RND_NONE) {
+            auto tx = c.textures.find(it.mat.texture);
+            if (tx != c.textures.end() && !tx->second.opaque) alpha_tex = &tx->second;
+        }
         parallel_for(c.threads, ntri, [&](size_t lo, size_t hi) {
             for (size_t t = lo; t < hi; ++t) {
                 uint32_t id = it.tri_base + (uint32_t)t;
@@ -697,6 +703,18 @@ static int render(Ctx& c) {
                                 [&](uint32_t i, uint32_t j, float z) {
                                     if (!(z < 1.0f)) return;            // depth Less against clear 1.0
                                     if (!owns_pixel(c, i, j)) return;
+                                    if (alpha_tex) {
+                                        const Vertex& va = s.verts[s.idx[3 * t]], &vb = s.verts[s.idx[3 * t + 1]], &vc = s.verts[s.idx[3 * t + 2]];
+                                        float b[3], dbx[3], dby[3];
+                                        barycentrics(it.clip[s.idx[3 * t]], it.clip[s.idx[3 * t + 1]], it.clip[s.idx[3 * t + 2]], i, j, W, H, b, dbx, dby);
+                                        Frag f{};
+                                        f.u = (b[0] * va.u + b[1] * vb.u) + b[2] * vc.u; f.v = (b[0] * va.v + b[1] * vb.v) + b[2] * vc.v;
+                                        f.dudx = (dbx[0] * va.u + dbx[1] * vb.u) + dbx[2] * vc.u; f.dvdx = (dbx[0] * va.v + dbx[1] * vb.v) + dbx[2] * vc.v;
+                                        f.dudy = (dby[0] * va.u + dby[1] * vb.u) + dby[2] * vc.u; f.dvdy = (dby[0] * va.v + dby[1] * vb.v) + dby[2] * vc.v;
+                                        float texel[4];
+                                        sample_texture(*alpha_tex, f, texel);
+                                        if (it.mat.base[3] * texel[3] < 0.5f) return;
+                                    }
                                     atomic_min(vis[(size_t)j * W + i], ((uint64_t)fbits(z) << 32) | id);
                                 });
             }
@@ -950,7 +968,6 @@ int orc_register_texture(rnd_ctx* ctx, uint32_t id, uint32_t w, uint32_t h, uint
         t.texels[4 * k + 3] = (float)(data[4 * k + 3] / 255.0);
         if (data[4 * k + 3] != 255) t.opaque = false;
     }
-    if (!t.opaque) { c->err = "textures with alpha below 1 (per-fragment alpha test) are not built yet (SURVEY 8f N2)"; return RND_ERR_UNSUPPORTED; }
     c->textures[id] = std::move(t);
     return RND_OK;
 }

@@ -26,6 +26,7 @@ enum : uint32_t {
     kItemUnlit = 4u,                // MaterialUniform.unlit (visual_server.rs:983)
     kItemSkip = 8u,                 // alpha test fails for every fragment (base.a < 0.5, untextured)
     kItemCastsShadows = 16u,        // RenderMeshInstance.casts_shadows (visual_server.rs:961)
+    kItemAlphaTest = 32u,           // the texture has alpha below 1: base.a < 0.5 is decided per fragment
 };
 
 // A run of kChunkTris consecutive triangles of a submesh, described once at registration: the
@@ -88,7 +89,8 @@ struct ShadowSet {
 // largest first, level l being max(1, width >> l) x max(1, height >> l).
 struct TextureDesc {
     const float* texels;
-    uint32_t width, height, mips, pad;
+    uint32_t width, height, mips;
+    uint32_t opaque;                // every texel alpha == 1
 };
 static_assert(sizeof(TextureDesc) == 24, "TextureDesc layout");
 
@@ -116,7 +118,7 @@ struct SetupRecord {
     float z0, dz1, dz2;                // depth at v0 and deltas to v1, v2
     float inv_area;                    // 1 / (double area in sub-pixel units)
     uint32_t tri_id;                   // draw-order id of the source triangle
-    uint32_t flags;                    // bit 0: bbox below 64 px in x and y (32-bit edge functions are exact)
+    uint32_t flags;                    // bit 0: bbox below 64 px in x and y (32-bit edge functions are exact); bit 1: fragments take the texture alpha test
 };
 static_assert(sizeof(SetupRecord) == 48, "SetupRecord is 3 x 16 bytes");
 

@@ -19,6 +19,7 @@ struct FrameBuffers {
     const GpuLight* lights;
     const ShadowSet* shadow_sets;   // indexed by GpuLight::shadow_index
     const TextureDesc* textures;    // indexed by DrawItem::texture
+    uint32_t alpha_test;            // some draw item has kItemAlphaTest: launch the raster variants with the test
     const uint32_t* unit_bases;     // n_items + 1: first work unit of each item
     uint2* active_units;            // (item, chunk) of the work units that survived k_cull
     uint32_t* vblock_needed;        // per kVertexBlock block of the frame's vertex slots: used by a surviving unit

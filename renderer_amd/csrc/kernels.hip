@@ -302,6 +302,85 @@ __device__ __forceinline__ bool any_owned(const TileRect& t, const FrameConst& f
 
 constexpr uint32_t kSmallPixels = 16;
 
+// textureSample with the reference's "filtered" sampler (backend.rs:414-426: Repeat, linear
+// mag/min/mip), restated isotropically as in the oracle: rho = longer pixel footprint in texels,
+// lambda = log2(rho) clamped to [0, mips-1], bilinear taps at floor(x - 0.5), two levels blended.
+__device__ __forceinline__ f32x4 texture_bilinear(const TextureDesc& t, uint32_t level, float u, float v) {
+    const uint32_t wl = max(1u, t.width >> level), hl = max(1u, t.height >> level);
+    size_t off = 0;
+    for (uint32_t l = 0; l < level; ++l) off += (size_t)max(1u, t.width >> l) * max(1u, t.height >> l);
+    const float x = u * (float)wl - 0.5f, y = v * (float)hl - 0.5f;
+    const float xf = floorf(x), yf = floorf(y);
+    const float fx = x - xf, fy = y - yf;
+    auto wrap = [](float f, uint32_t n) {
+        long long k = (long long)f % (long long)n;
+        return (uint32_t)(k < 0 ? k + (long long)n : k);
+    };
+    const uint32_t x0 = wrap(xf, wl), x1 = wrap(xf + 1.0f, wl), y0 = wrap(yf, hl), y1 = wrap(yf + 1.0f, hl);
+    gptr_f32x4 base = (gptr_f32x4)t.texels + off;
+    const f32x4 t00 = base[(size_t)y0 * wl + x0], t10 = base[(size_t)y0 * wl + x1];
+    const f32x4 t01 = base[(size_t)y1 * wl + x0], t11 = base[(size_t)y1 * wl + x1];
+    const f32x4 top = t00 * (1.0f - fx) + t10 * fx, bot = t01 * (1.0f - fx) + t11 * fx;
+    return top * (1.0f - fy) + bot * fy;
+}
+__device__ __forceinline__ f32x4 texture_sample(const TextureDesc& t, float u, float v, float dudx, float dvdx,
+                                                float dudy, float dvdy) {
+    const float ax = dudx * (float)t.width, ay = dvdx * (float)t.height, bx = dudy * (float)t.width, by = dvdy * (float)t.height;
+    const float rho2 = fmaxf(ax * ax + ay * ay, bx * bx + by * by);
+    float lambda = 0.5f * log2f(rho2);
+    lambda = (lambda != lambda) ? 0.0f : fminf(fmaxf(lambda, 0.0f), (float)(t.mips - 1u));
+    const float lf = floorf(lambda), frac = lambda - lf;
+    const uint32_t l0 = (uint32_t)lf, l1 = min(l0 + 1u, t.mips - 1u);
+    f32x4 a = texture_bilinear(t, l0, u, v);
+    if (frac > 0.0f) {
+        const f32x4 b = texture_bilinear(t, l1, u, v);
+        a = a * (1.0f - frac) + b * frac;
+    }
+    return a;
+}
+
+// The alpha test of a textured fragment (render_mesh.wgsl:89-92, :142-146: base = material.base_color *
+// textureSample(...); base.a < 0.5 discards), for draw items whose texture has alpha below 1.  Runs
+// in the raster stage, before the fragment may enter the (depth, id) resolve: the triangle's clip
+// positions and uv are fetched again from the id, barycentrics and the uv footprint as at shade time.
+__device__ __forceinline__ bool alpha_pass(const FrameBuffers& fb, const FrameConst& fc, uint32_t id, uint32_t i, uint32_t j) {
+    const uint32_t it = find_item(fb.tri_bases, fc.n_items, id);
+    const DrawItem& d = fb.items[it];
+    const uint32_t tex = d.texture;
+    if (tex == RND_NONE) return !(d.base_color[3] < 0.5f);
+    uint32_t t = id - d.tri_base;
+    if (t >= d.n_tris || d.n_verts == 0u) return true;
+    gptr_u32 ix = (gptr_u32)d.indices + 3ull * t;
+    const uint32_t last_v = d.n_verts - 1u, last_c = max(fc.n_verts, 1u) - 1u;
+    const uint32_t i0 = min(ix[0], last_v), i1 = min(ix[1], last_v), i2 = min(ix[2], last_v);
+    gptr_f32x4 vp = (gptr_f32x4)d.verts;
+    const f32x4 a1 = vp[2ull * i0 + 1], b1v = vp[2ull * i1 + 1], c1v = vp[2ull * i2 + 1];
+    const float4 c0 = fb.clip[min(d.vert_base + i0, last_c)], c1 = fb.clip[min(d.vert_base + i1, last_c)],
+                 c2 = fb.clip[min(d.vert_base + i2, last_c)];
+    const float u0 = a1.z, v0 = a1.w, u1 = b1v.z, v1 = b1v.w, u2 = c1v.z, v2 = c1v.w;
+    const float xn = fmaf((float)i + 0.5f, fc.ndc_step_xf, -1.0f), yn = fmaf(-((float)j + 0.5f), fc.ndc_step_yf, 1.0f);
+    const float px0 = fmaf(-xn, c0.w, c0.x), py0 = fmaf(-yn, c0.w, c0.y);
+    const float px1 = fmaf(-xn, c1.w, c1.x), py1 = fmaf(-yn, c1.w, c1.y);
+    const float px2 = fmaf(-xn, c2.w, c2.x), py2 = fmaf(-yn, c2.w, c2.y);
+    const float f0 = fmaf(px1, py2, -(px2 * py1)), f1 = fmaf(px2, py0, -(px0 * py2)), f2 = fmaf(px0, py1, -(px1 * py0));
+    const float S = (f0 + f1) + f2;
+    const float is = 1.0f / S;
+    float b0 = f0 * is, b1 = f1 * is, b2 = f2 * is;
+    if (!(fabsf(b0) + fabsf(b1) + fabsf(b2) < 3.0e38f)) { b0 = 1.0f; b1 = 0.0f; b2 = 0.0f; }
+    const float ax0 = c2.w * py1 - c1.w * py2, ax1 = c0.w * py2 - c2.w * py0, ax2 = c1.w * py0 - c0.w * py1;
+    const float ay0 = px2 * c1.w - px1 * c2.w, ay1 = px0 * c2.w - px2 * c0.w, ay2 = px1 * c0.w - px0 * c1.w;
+    const float Sx = (ax0 + ax1) + ax2, Sy = (ay0 + ay1) + ay2;
+    const float is2 = is * is, kx = is2 * fc.ndc_step_xf, ky = is2 * (-fc.ndc_step_yf);
+    float dx0 = (ax0 * S - f0 * Sx) * kx, dx1 = (ax1 * S - f1 * Sx) * kx, dx2 = (ax2 * S - f2 * Sx) * kx;
+    float dy0 = (ay0 * S - f0 * Sy) * ky, dy1 = (ay1 * S - f1 * Sy) * ky, dy2 = (ay2 * S - f2 * Sy) * ky;
+    if (!(fabsf(dx0) + fabsf(dx1) + fabsf(dx2) + fabsf(dy0) + fabsf(dy1) + fabsf(dy2) < 3.0e38f)) dx0 = dx1 = dx2 = dy0 = dy1 = dy2 = 0.0f;
+    const float uu = (b0 * u0 + b1 * u1) + b2 * u2, vv = (b0 * v0 + b1 * v1) + b2 * v2;
+    const float dudx = (dx0 * u0 + dx1 * u1) + dx2 * u2, dvdx = (dx0 * v0 + dx1 * v1) + dx2 * v2;
+    const float dudy = (dy0 * u0 + dy1 * u1) + dy2 * u2, dvdy = (dy0 * v0 + dy1 * v1) + dy2 * v2;
+    const f32x4 texel = texture_sample(fb.textures[tex], uu, vv, dudx, dvdx, dudy, dvdy);
+    return !(d.base_color[3] * texel.w < 0.5f);
+}
+
 // fragment sinks: where a covered sample's (depth, triangle id) key is min-resolved
 struct LdsSink {
     unsigned long long* s_vis;
@@ -336,9 +415,9 @@ struct GlobalSink {
     }
 };
 
-template <class Sink>
+template <bool kAlpha, class Sink>
 __device__ __forceinline__ void raster_small(const SetupRecord& r, int32_t i0, int32_t i1, int32_t j0, int32_t j1,
-                                             const Sink& sink) {
+                                             const Sink& sink, const FrameBuffers& fb, const FrameConst& fc) {
     // inside-positive edges: w0 = F(v2,v1,p), w1 = F(v0,v2,p), w2 = F(v1,v0,p)
     const int32_t ex0 = r.x1 - r.x2, ey0 = r.y1 - r.y2;
     const int32_t ex1 = r.x2 - r.x0, ey1 = r.y2 - r.y0;
@@ -358,7 +437,9 @@ __device__ __forceinline__ void raster_small(const SetupRecord& r, int32_t i0, i
             if (w0 >= b0 && w1 >= b1 && w2 >= b2) {
                 float l1 = (float)w1 * r.inv_area, l2 = (float)w2 * r.inv_area;
                 float z = (l1 * r.dz1 + l2 * r.dz2) + r.z0;
-                sink(i, j, z, r.tri_id);
+                bool pass = true;
+                if constexpr (kAlpha) pass = !(r.flags & 2u) || alpha_pass(fb, fc, r.tri_id, (uint32_t)i, (uint32_t)j);
+                if (pass) sink(i, j, z, r.tri_id);
             }
             w0 -= ey0 * kSub; w1 -= ey1 * kSub; w2 -= ey2 * kSub;
         }
@@ -448,7 +529,7 @@ struct DirectTri {                  // 20 dwords = 5 x 16 B
     int32_t r0, r1, r2;             // edge functions at the bbox's first pixel centre
     int32_t sx0, sx1, sx2;          // ex * 256: step per pixel row
     int32_t sy0, sy1, sy2;          // ey * 256: step per pixel column (subtracted)
-    uint32_t shape;                 // bbox width | pixel count << 8 | top-left bias bits << 16
+    uint32_t shape;                 // bbox width | pixel count << 8 | top-left bias bits << 16 | alpha test << 19
     float z0, dz1, dz2, inv_area;
     uint32_t id;
     uint32_t origin;                // i0 | j0 << 16
@@ -473,7 +554,7 @@ __device__ __forceinline__ DirectTri make_direct(const SetupRecord& r, const Til
     d.sx0 = ex0 * kSub; d.sx1 = ex1 * kSub; d.sx2 = ex2 * kSub;
     d.sy0 = ey0 * kSub; d.sy1 = ey1 * kSub; d.sy2 = ey2 * kSub;
     const uint32_t w = (uint32_t)(t.i1 - t.i0 + 1), h = (uint32_t)(t.j1 - t.j0 + 1);
-    d.shape = w | ((w * h) << 8) | (b0 << 16) | (b1 << 17) | (b2 << 18);
+    d.shape = w | ((w * h) << 8) | (b0 << 16) | (b1 << 17) | (b2 << 18) | (((r.flags >> 1) & 1u) << 19);
     d.z0 = r.z0; d.dz1 = r.dz1; d.dz2 = r.dz2; d.inv_area = r.inv_area;
     d.id = r.tri_id;
     d.origin = (uint32_t)t.i0 | ((uint32_t)t.j0 << 16);
@@ -483,8 +564,9 @@ __device__ __forceinline__ DirectTri make_direct(const SetupRecord& r, const Til
 }
 
 // pixel k (row-major in the bbox) of a compacted triangle
-template <class Sink>
-__device__ __forceinline__ void direct_pixel(const DirectTri& d, uint32_t k, const Sink& sink) {
+template <bool kAlpha, class Sink>
+__device__ __forceinline__ void direct_pixel(const DirectTri& d, uint32_t k, const Sink& sink, const FrameBuffers& fb,
+                                             const FrameConst& fc) {
     const uint32_t w = d.shape & 255u;
     // k / w for k < 16, w <= 16: (k + 0.5) / w is at least 1/32 away from an integer, far beyond the
     // 1 ulp of the approximate reciprocal
@@ -497,7 +579,10 @@ __device__ __forceinline__ void direct_pixel(const DirectTri& d, uint32_t k, con
     if (w0 >= b0 && w1 >= b1 && w2 >= b2) {
         const float l1 = (float)w1 * d.inv_area, l2 = (float)w2 * d.inv_area;
         const float z = (l1 * d.dz1 + l2 * d.dz2) + d.z0;
-        sink((int32_t)((d.origin & 0xFFFFu) + di), (int32_t)((d.origin >> 16) + dj), z, d.id);
+        const uint32_t i = (d.origin & 0xFFFFu) + di, j = (d.origin >> 16) + dj;
+        bool pass = true;
+        if constexpr (kAlpha) pass = !((d.shape >> 19) & 1u) || alpha_pass(fb, fc, d.id, i, j);
+        if (pass) sink((int32_t)i, (int32_t)j, z, d.id);
     }
 }
 
@@ -512,6 +597,8 @@ constexpr uint32_t kSetupChunk = kChunkTris;
 
 // One workgroup per surviving work unit (draw item, chunk of kChunkTris triangles): the item is
 // uniform for the whole workgroup, so its fields come in through scalar loads.
+// kAlpha: some draw item of the frame takes the per-fragment texture alpha test (compiled out otherwise)
+template <bool kAlpha>
 __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, FrameConst fc, Capacities cap) {
     __shared__ uint32_t s_used;         // record slots of this workgroup's chunk handed out so far
     __shared__ uint32_t s_valid[4];
@@ -529,6 +616,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, FrameConst fc, C
     const uint32_t item_tris = d->n_tris;
     const uint32_t n_here = item_tris > first_t ? min(item_tris - first_t, kSetupChunk) : 0u;
     const uint32_t vb = d->vert_base, nv = d->n_verts, tri_base = d->tri_base;
+    const bool alpha_item = (d->flags & kItemAlphaTest) != 0u;       // fragments take the texture alpha test
     gptr_u32 indices = (gptr_u32)d->indices;
     const bool tables_ok = guard(vb + nv <= fc.n_verts, fb.counters, kGuardSetup);
     const uint32_t chunk_base = blockIdx.x * kSetupChunk;
@@ -550,6 +638,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, FrameConst fc, C
                 const float4 c1 = fb.clip[vb + i1];
                 const float4 c2 = fb.clip[vb + i2];
                 setup_triangle(c0, c1, c2, gid, fc, half_w, half_h, rec, tr, emit, need_clip);
+                if (alpha_item) rec.flags |= 2u;
             }
         }
         // queue the triangles that need the clipper (wave-compacted, rare)
@@ -591,7 +680,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, FrameConst fc, C
                     const uint4* src = s_direct[wave][which];
                     dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3]; dst[4] = src[4];
                     const uint32_t npix = (dt.shape >> 8) & 255u;
-                    for (uint32_t k = lane & 3u; k < npix; k += 4u) direct_pixel(dt, k, direct_sink);
+                    for (uint32_t k = lane & 3u; k < npix; k += 4u) direct_pixel<kAlpha>(dt, k, direct_sink, fb, fc);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -683,6 +772,7 @@ __global__ __launch_bounds__(256) void k_clip(FrameBuffers fb, FrameConst fc, Ca
             SetupRecord rec;
             TileRect tr;
             if (!make_record(s[0], s[k], s[k + 1], gid, fc, rec, tr) || !any_owned(tr, fc)) continue;
+            if (d.flags & kItemAlphaTest) rec.flags |= 2u;
             uint32_t slot = cap.setup_slots + atomicAdd(&fb.counters->n_records, 1u);
             if (slot >= cap.records) { atomicOr(&fb.counters->overflow, 1u); continue; }
             atomicAdd(&fb.counters->n_valid, 1u);
@@ -818,8 +908,9 @@ __global__ __launch_bounds__(256) void k_bin_fill(FrameBuffers fb, FrameConst fc
 // lane each with 32-bit edge functions; the rest are queued in LDS and swept by a whole wave in
 // 8x8 pixel blocks with 64-bit edge functions.
 // ------------------------------------------------------------------------------------------
+template <bool kAlpha>
 __device__ __forceinline__ void raster_wave(const SetupRecord& r, int32_t i0, int32_t i1, int32_t j0, int32_t j1,
-                                            const LdsSink& sink) {
+                                            const LdsSink& sink, const FrameBuffers& fb, const FrameConst& fc) {
     const uint32_t lane = lane_id();
     const int32_t lx = (int32_t)(lane & 7u), ly = (int32_t)(lane >> 3);
     const int32_t ex0 = r.x1 - r.x2, ey0 = r.y1 - r.y2;
@@ -839,7 +930,9 @@ __device__ __forceinline__ void raster_wave(const SetupRecord& r, int32_t i0, in
             if (w0 >= b0 && w1 >= b1 && w2 >= b2) {
                 float l1 = (float)w1 * r.inv_area, l2 = (float)w2 * r.inv_area;
                 float z = (l1 * r.dz1 + l2 * r.dz2) + r.z0;
-                sink(i, j, z, r.tri_id);
+                bool pass = true;
+                if constexpr (kAlpha) pass = !(r.flags & 2u) || alpha_pass(fb, fc, r.tri_id, (uint32_t)i, (uint32_t)j);
+                if (pass) sink(i, j, z, r.tri_id);
             }
         }
 }
@@ -852,6 +945,7 @@ __device__ __forceinline__ SetupRecord load_record(const SetupRecord* __restrict
     return r;
 }
 
+template <bool kAlpha>
 __global__ __launch_bounds__(256) void k_raster(FrameBuffers fb, FrameConst fc, Capacities cap) {
     __shared__ unsigned long long s_vis[kTilePixels];
     __shared__ uint32_t s_big[256];
@@ -884,7 +978,7 @@ __global__ __launch_bounds__(256) void k_raster(FrameBuffers fb, FrameConst fc, 
             int32_t j1 = min((ymax - kSub / 2) >> kSubpixelBits, tile_y1);
             if (i0 <= i1 && j0 <= j1) {
                 uint32_t npix = (uint32_t)(i1 - i0 + 1) * (uint32_t)(j1 - j0 + 1);
-                if ((r.flags & 1u) && npix <= kSmallPixels) raster_small(r, i0, i1, j0, j1, sink);
+                if ((r.flags & 1u) && npix <= kSmallPixels) raster_small<kAlpha>(r, i0, i1, j0, j1, sink, fb, fc);
                 else s_big[atomicAdd(&s_nbig, 1u)] = slot;
             }
         }
@@ -898,7 +992,7 @@ __global__ __launch_bounds__(256) void k_raster(FrameBuffers fb, FrameConst fc, 
             int32_t i1 = min((xmax - kSub / 2) >> kSubpixelBits, tile_x1);
             int32_t j0 = max((ymin - kSub / 2 + kSub - 1) >> kSubpixelBits, tile_y0);
             int32_t j1 = min((ymax - kSub / 2) >> kSubpixelBits, tile_y1);
-            raster_wave(r, i0, i1, j0, j1, sink);
+            raster_wave<kAlpha>(r, i0, i1, j0, j1, sink, fb, fc);
         }
         __syncthreads();
     }
@@ -951,43 +1045,6 @@ __device__ __forceinline__ uint32_t srgb8_f(float lin) {
 #else
     return srgb8(lin);
 #endif
-}
-
-// textureSample with the reference's "filtered" sampler (backend.rs:414-426: Repeat, linear
-// mag/min/mip), restated isotropically as in the oracle: rho = longer pixel footprint in texels,
-// lambda = log2(rho) clamped to [0, mips-1], bilinear taps at floor(x - 0.5), two levels blended.
-__device__ __forceinline__ f32x4 texture_bilinear(const TextureDesc& t, uint32_t level, float u, float v) {
-    const uint32_t wl = max(1u, t.width >> level), hl = max(1u, t.height >> level);
-    size_t off = 0;
-    for (uint32_t l = 0; l < level; ++l) off += (size_t)max(1u, t.width >> l) * max(1u, t.height >> l);
-    const float x = u * (float)wl - 0.5f, y = v * (float)hl - 0.5f;
-    const float xf = floorf(x), yf = floorf(y);
-    const float fx = x - xf, fy = y - yf;
-    auto wrap = [](float f, uint32_t n) {
-        long long k = (long long)f % (long long)n;
-        return (uint32_t)(k < 0 ? k + (long long)n : k);
-    };
-    const uint32_t x0 = wrap(xf, wl), x1 = wrap(xf + 1.0f, wl), y0 = wrap(yf, hl), y1 = wrap(yf + 1.0f, hl);
-    gptr_f32x4 base = (gptr_f32x4)t.texels + off;
-    const f32x4 t00 = base[(size_t)y0 * wl + x0], t10 = base[(size_t)y0 * wl + x1];
-    const f32x4 t01 = base[(size_t)y1 * wl + x0], t11 = base[(size_t)y1 * wl + x1];
-    const f32x4 top = t00 * (1.0f - fx) + t10 * fx, bot = t01 * (1.0f - fx) + t11 * fx;
-    return top * (1.0f - fy) + bot * fy;
-}
-__device__ __forceinline__ f32x4 texture_sample(const TextureDesc& t, float u, float v, float dudx, float dvdx,
-                                                float dudy, float dvdy) {
-    const float ax = dudx * (float)t.width, ay = dvdx * (float)t.height, bx = dudy * (float)t.width, by = dvdy * (float)t.height;
-    const float rho2 = fmaxf(ax * ax + ay * ay, bx * bx + by * by);
-    float lambda = 0.5f * log2f(rho2);
-    lambda = (lambda != lambda) ? 0.0f : fminf(fmaxf(lambda, 0.0f), (float)(t.mips - 1u));
-    const float lf = floorf(lambda), frac = lambda - lf;
-    const uint32_t l0 = (uint32_t)lf, l1 = min(l0 + 1u, t.mips - 1u);
-    f32x4 a = texture_bilinear(t, l0, u, v);
-    if (frac > 0.0f) {
-        const f32x4 b = texture_bilinear(t, l1, u, v);
-        a = a * (1.0f - frac) + b * frac;
-    }
-    return a;
 }
 
 // Monotone map f32 -> u32 (and back) so float min/max run as integer min/max over DPP row
@@ -1526,7 +1583,8 @@ void launch_transform(const FrameBuffers& fb, const FrameConst& fc, hipStream_t 
 }
 void launch_setup(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {
     if (!fc.n_tris) return;
-    hipLaunchKernelGGL(k_setup, dim3(fc.n_units), dim3(256), 0, stream, fb, fc, cap);
+    if (fb.alpha_test) hipLaunchKernelGGL(k_setup<true>, dim3(fc.n_units), dim3(256), 0, stream, fb, fc, cap);
+    else hipLaunchKernelGGL(k_setup<false>, dim3(fc.n_units), dim3(256), 0, stream, fb, fc, cap);
 }
 void launch_clip(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {
     if (!fc.n_tris) return;
@@ -1543,7 +1601,8 @@ void launch_bin(const FrameBuffers& fb, const FrameConst& fc, const Capacities& 
 }
 void launch_raster(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {
     if (!fb.n_owned) return;
-    hipLaunchKernelGGL(k_raster, dim3(fb.n_owned), dim3(256), 0, stream, fb, fc, cap);
+    if (fb.alpha_test) hipLaunchKernelGGL(k_raster<true>, dim3(fb.n_owned), dim3(256), 0, stream, fb, fc, cap);
+    else hipLaunchKernelGGL(k_raster<false>, dim3(fb.n_owned), dim3(256), 0, stream, fb, fc, cap);
 }
 void launch_shade(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream) {
     if (!fb.n_owned) return;

@@ -236,8 +236,8 @@ void VisualServer::register_material(uint32_t id, const Material& m) {
 // register_texture / update_texture (visual_server.rs:752-769): an Rgba8UnormSrgb texture with the
 // caller's mip chain (backend.rs:358-383).  Stored decoded: RGBA f32 per texel, rgb through the sRGB
 // EOTF (evaluated in f64, rounded once), so the shading kernel filters linear values as the
-// hardware sampler does.  Textures with any alpha below 255 would need the per-fragment alpha test
-// (render_mesh.wgsl:91) in the raster stage: not built yet.
+// hardware sampler does.  A texture with any alpha below 255 marks the draw items that use it for the
+// per-fragment alpha test (render_mesh.wgsl:91) in the raster stage.
 void VisualServer::register_texture(uint32_t id, uint32_t w, uint32_t h, uint32_t mips, const uint8_t* data) {
     if (id == RND_NONE || !w || !h || !mips || !data || w > 16384 || h > 16384) throw Error(RND_ERR_INVALID, "bad texture");
     uint32_t max_levels = 1;
@@ -251,13 +251,13 @@ void VisualServer::register_texture(uint32_t id, uint32_t w, uint32_t h, uint32_
         const double c = v / 255.0;
         lut[v] = c <= 0.04045 ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4);
     }
+    bool opaque = true;
     for (size_t k = 0; k < total; ++k) {
-        if (data[4 * k + 3] != 255)
-            throw Error(RND_ERR_UNSUPPORTED, "textures with alpha below 1 (per-fragment alpha test) are not built yet (SURVEY 8f N2)");
         texels[4 * k + 0] = (float)lut[data[4 * k + 0]];
         texels[4 * k + 1] = (float)lut[data[4 * k + 1]];
         texels[4 * k + 2] = (float)lut[data[4 * k + 2]];
-        texels[4 * k + 3] = 1.0f;
+        texels[4 * k + 3] = (float)(data[4 * k + 3] / 255.0);
+        opaque = opaque && data[4 * k + 3] == 255;
     }
     use_device();
     finish();
@@ -265,14 +265,14 @@ void VisualServer::register_texture(uint32_t id, uint32_t w, uint32_t h, uint32_
     const bool is_new = t.mips == 0;
     t.texels.ensure(texels.size());
     HIP_CHECK(hipMemcpy(t.texels.ptr, texels.data(), texels.size() * sizeof(float), hipMemcpyHostToDevice));
-    t.width = w; t.height = h; t.mips = mips;
+    t.width = w; t.height = h; t.mips = mips; t.opaque = opaque;
     if (is_new) t.slot = (uint32_t)textures_.size() - 1;
     upload_texture_table();
 }
 
 void VisualServer::upload_texture_table() {
     std::vector<TextureDesc> table(std::max<size_t>(textures_.size(), 1), TextureDesc{nullptr, 0, 0, 0, 0});
-    for (const auto& kv : textures_) table.at(kv.second.slot) = TextureDesc{kv.second.texels.ptr, kv.second.width, kv.second.height, kv.second.mips, 0};
+    for (const auto& kv : textures_) table.at(kv.second.slot) = TextureDesc{kv.second.texels.ptr, kv.second.width, kv.second.height, kv.second.mips, kv.second.opaque ? 1u : 0u};
     d_textures_.ensure(table.size());
     HIP_CHECK(hipMemcpy(d_textures_.ptr, table.data(), table.size() * sizeof(TextureDesc), hipMemcpyHostToDevice));
 }
@@ -341,6 +341,7 @@ void VisualServer::build_frame(std::vector<DrawItem>& items, std::vector<uint32_
                                std::vector<GpuLight>& lights, std::vector<DrawItem>& shadow_items) {
     const Mat4 pv = projection_ * view_;
     uint64_t vert_base = 0, tri_base = 0, unit_base = 0;
+    frame_alpha_test_ = false;
     // for mesh_instance { for submesh } — visual_server.rs:227-245
     for (const RenderMeshInstance& inst : mesh_instances_) {
         const RenderMesh& mesh = meshes_.at(inst.mesh);
@@ -380,6 +381,7 @@ void VisualServer::build_frame(std::vector<DrawItem>& items, std::vector<uint32_
                 auto tex = textures_.find(mat.texture);
                 if (tex == textures_.end()) throw Error(RND_ERR_UNKNOWN_ID, "texture id not registered");
                 d.texture = tex->second.slot;
+                if (!tex->second.opaque && !(d.flags & kItemSkip)) { d.flags |= kItemAlphaTest; frame_alpha_test_ = true; }
             }
             d.chunks = s.chunks.ptr; d.n_chunks = s.n_chunks; d.unit_base = (uint32_t)unit_base;
             vert_bases.push_back(d.vert_base);
@@ -540,6 +542,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     FrameBuffers fb{};
     fb.items = d_items_.ptr; fb.vert_bases = d_vert_bases_.ptr; fb.tri_bases = d_tri_bases_.ptr; fb.lights = d_lights_.ptr;
     fb.textures = d_textures_.ptr;
+    fb.alpha_test = frame_alpha_test_ ? 1u : 0u;
     fb.shadow_sets = n_sets ? d_shadow_sets_.ptr : nullptr;      // null selects the shading kernel without the lookup
     fb.clip = d_clip_.ptr; fb.records = d_records_.ptr; fb.tilewords = reinterpret_cast<uint2*>(d_tilewords_.ptr); fb.clip_queue = d_clip_queue_.ptr;
     fb.chunk_count = d_chunk_count_.ptr;
@@ -564,7 +567,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     for (uint32_t k = 0; k < n_sets; ++k)
         for (uint32_t c = 0; c < kShadowCascades; ++c) {
             FrameBuffers sfb = fb;
-            sfb.items = d_shadow_items_.ptr; sfb.lights = nullptr; sfb.shadow_sets = nullptr;
+            sfb.items = d_shadow_items_.ptr; sfb.lights = nullptr; sfb.shadow_sets = nullptr; sfb.alpha_test = 0;
             sfb.counters = d_counters_.ptr + 1 + k * kShadowCascades + c;
             sfb.launch_order = d_shadow_order_.ptr; sfb.n_owned = kShadowTiles;
             sfb.vis = shadow_layers_[k].ptr + (size_t)c * kShadowTiles * kTilePixels;

@@ -63,6 +63,7 @@ struct RenderTexture {           // RenderScene::textures (visual_server.rs:901)
     DeviceBuffer<float> texels;
     uint32_t width = 0, height = 0, mips = 0;
     uint32_t slot = 0;           // index into the device texture table
+    bool opaque = true;          // every alpha == 255
 };
 struct RenderLight {
     UniqueNodeId id; Mat4 transform; Light light;
@@ -146,6 +147,7 @@ private:
     int device_;
     uint32_t width_, height_;            // the 3D render target: surface * render_size_factor, truncated
     uint32_t surface_w_ = 0, surface_h_ = 0;
+    bool frame_alpha_test_ = false;      // set by build_frame
     void apply_size(uint32_t sw, uint32_t sh, float factor);
     bool scaled() const { return width_ != surface_w_ || height_ != surface_h_; }
     DeviceBuffer<uint8_t> d_present_;     // surface-sized RGBA8 when scaled()

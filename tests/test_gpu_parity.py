@@ -282,3 +282,37 @@ def test_render_size_factor(factor):
         vs.set_render_size_factor(1.0)
         vs.render()
     assert_parity(gpu, cpu, min_covered=3000)
+
+
+def test_cutout_texture_alpha_test_and_sprites():
+    """N2/N3: textures with alpha — the per-fragment alpha test in the raster stage (direct path, bins and
+    clipper alike) — on a height-field, a large quad crossing the near plane, and billboard sprites."""
+    from renderer_amd.types import Image, Material
+    s = c2_grid_1m(width=360, height=200, scale=0.1)
+    r = np.random.default_rng(33)
+    px = r.integers(0, 256, (64, 64, 4)).astype(np.uint8)
+    yy, xx = np.mgrid[0:64, 0:64]
+    px[..., 3] = np.where(((xx - 32) ** 2 + (yy - 32) ** 2) < 24 ** 2, 255, 0)     # a disc
+    px[20:30, 20:44, 3] = 90                                                       # with a translucent bar
+    image = Image(64, 64, px).make_mips()
+    pair = []
+    for make in (lambda: VisualServer(s.width, s.height, device=0), lambda: oracle_server(s.width, s.height)):
+        vs = make()
+        tex = vs.asset_server.add(image)
+        mat = vs.asset_server.add(Material(base_color=Color(1.0, 0.9, 0.8, 1.0), base_color_image=tex))
+        for m in s.meshes:
+            for sub in m.submeshes:
+                sub.material = mat
+        quad = Mesh.quad()
+        quad.submeshes[0].material = mat
+        s.populate(vs)
+        qh = vs.asset_server.add(quad)
+        vs.set_mesh_instance(900, from_translation((0.2, -0.3, 1.0)) @ from_rotation_x(1.3) @ from_scale((4, 6, 1)), qh)
+        for k in range(5):
+            vs.set_sprite(950 + k, from_translation((-2 + k, 0.5, 3.0 + 0.3 * k)), tex, Color(1.0, 0.5 + 0.1 * k, 0.3, 1.0))
+        vs.render()
+        pair.append(vs)
+    gpu, cpu = pair
+    assert_parity(gpu, cpu, min_covered=10000, hdr=False)
+    cov = cpu.read_coverage()
+    assert 0.1 < cov.mean() < 0.9          # the cut-outs really cut

@@ -442,14 +442,37 @@ def test_ka14_texture_minified_eightfold_reads_mip_3():
     assert np.abs(out.astype(int) - level3.astype(int)).max() <= 1
 
 
-def test_ka15_texture_with_alpha_is_refused():
-    from renderer_amd import RndError
+def test_ka15_texture_alpha_test_per_fragment():
+    """base.a = material.a * texel.a < 0.5 discards the fragment (render_mesh.wgsl:89-92): with one texel
+    per pixel the coverage mask equals the texture's alpha >= 128 mask, and the pixels behind show
+    through (depth 1.0, clear colour)."""
     from renderer_amd.types import Image
-    px = np.full((4, 4, 4), 200, dtype=np.uint8)
-    vs = oracle_server(8, 8, threads=1)
-    tex = vs.asset_server.add(Image(4, 4, px))
-    with pytest.raises(RndError):
-        vs._register_texture(tex)
+    n = 16
+    r = np.random.default_rng(8)
+    px = r.integers(0, 256, (n, n, 4)).astype(np.uint8)
+    px[..., 3] = np.where(r.random((n, n)) < 0.5, 255, 0)
+    cam = Camera(aspect_ratio=1.0)
+    vs = oracle_server(n, n, threads=1)
+    vs.set_tone_mapping(0)
+    vs.set_camera(identity(), cam)
+    textured_quad_scene(vs, cam, n, Image(n, n, px), n, n)
+    vs.render()
+    cov = vs.read_coverage()
+    assert (cov == (px[..., 3] == 255)).all()
+    assert (vs.read_depth()[cov == 0] == 1.0).all()
+    out = vs.read_color_rgba8()
+    assert np.abs(out[cov == 1].astype(int) - px[cov == 1].astype(int)).max() <= 1
+    # material alpha scales it: 0.4 * 1.0 < 0.5 -> nothing is drawn at all
+    vs2 = oracle_server(n, n, threads=1)
+    vs2.set_camera(identity(), cam)
+    tex = vs2.asset_server.add(Image(n, n, px))
+    mat = vs2.asset_server.add(Material(base_color=Color(1, 1, 1, 0.4), base_color_image=tex, unlit=True))
+    pos = [screen_to_view(x, y, 2.0, n, n, cam) for x, y in [(0, 0), (n, 0), (0, n), (n, n)]]
+    mesh = vs2.asset_server.add(Mesh([Submesh(make_vertices(pos, uvs=[(0, 0), (1, 0), (0, 1), (1, 1)]),
+                                              np.array([0, 2, 1, 1, 2, 3], dtype=np.uint32), mat)]))
+    vs2.set_mesh_instance(1, identity(), mesh)
+    vs2.render()
+    assert vs2.read_coverage().sum() == 0
 
 
 # ---- KA16: render_size_factor (SURVEY.md 8f N4) ----------------------------------------------
