@@ -135,14 +135,17 @@ static int clip_polygon(ClipVert* poly, int n) {
 
 struct Snapped { int32_t X, Y; float z; };
 
-static inline bool snap_vertex(const ClipVert& v, float half_w, float half_h, Snapped& s) {
+// (sub_dx, sub_dy): whole sub-pixel steps added after the snap.  With MSAA, sample k of a pixel at
+// offset (ox, oy) from the pixel's corner is the pixel centre of the geometry moved by
+// (1/2 - ox, 1/2 - oy): every offset of the 4x pattern is a multiple of 1/16 px, exact on the grid.
+static inline bool snap_vertex(const ClipVert& v, float half_w, float half_h, Snapped& s, int32_t sub_dx = 0, int32_t sub_dy = 0) {
     if (!(v.w > 0.0f)) return false;
     float rw = 1.0f / v.w;
     float nx = v.x * rw, ny = v.y * rw, nz = v.z * rw;
     float sx = (nx + 1.0f) * half_w;          // x_fb = (x_ndc + 1) * W/2
     float sy = (1.0f - ny) * half_h;          // y_fb = (1 - y_ndc) * H/2   (y down)
-    s.X = (int32_t)std::nearbyint(sx * (float)SUB);   // round to nearest even, 8 sub-pixel bits
-    s.Y = (int32_t)std::nearbyint(sy * (float)SUB);
+    s.X = (int32_t)std::nearbyint(sx * (float)SUB) + sub_dx;   // round to nearest even, 8 sub-pixel bits
+    s.Y = (int32_t)std::nearbyint(sy * (float)SUB) + sub_dy;
     s.z = nz;
     return true;
 }
@@ -201,7 +204,7 @@ static void raster_snapped(const Snapped& a, const Snapped& b, const Snapped& c,
 
 template <class F>
 static void raster_triangle(const V4& c0, const V4& c1, const V4& c2, uint32_t W, uint32_t H,
-                            F&& frag) {
+                            F&& frag, int32_t sub_dx = 0, int32_t sub_dy = 0) {
     ClipVert v[12] = {{c0.x, c0.y, c0.z, c0.w}, {c1.x, c1.y, c1.z, c1.w}, {c2.x, c2.y, c2.z, c2.w}};
     for (int k = 0; k < 3; ++k)
         if (!(std::isfinite(v[k].x) && std::isfinite(v[k].y) && std::isfinite(v[k].z) &&
@@ -225,7 +228,7 @@ static void raster_triangle(const V4& c0, const V4& c1, const V4& c2, uint32_t W
     float half_w = 0.5f * (float)W, half_h = 0.5f * (float)H;
     Snapped s[12];
     for (int k = 0; k < n; ++k)
-        if (!snap_vertex(v[k], half_w, half_h, s[k])) return;
+        if (!snap_vertex(v[k], half_w, half_h, s[k], sub_dx, sub_dy)) return;
     for (int k = 1; k + 1 < n; ++k) raster_snapped(s[0], s[k], s[k + 1], W, H, frag);
 }
 
@@ -682,8 +685,16 @@ static int render(Ctx& c) {
     // K2+K3: visibility (nearest fragment; ties -> lowest triangle id = first in draw order).
     // Materials whose alpha test fails for every fragment (untextured, base.a < 0.5) draw nothing
     // (render_mesh.wgsl:91-92, :144-146).
-    std::vector<std::atomic<uint64_t>> vis(P);
-    for (size_t k = 0; k < P; ++k) vis[k].store(CLEAR_KEY, std::memory_order_relaxed);
+    // MSAA (sample_count 4, visual_server.rs:174-181): one visibility plane per sample, the standard 4x
+    // pattern (offsets from the pixel corner in 1/16 px); coverage and depth are per sample, the
+    // fragment stage (alpha test, shading) runs once per pixel at its centre.
+    const uint32_t S = c.msaa;
+    static const int32_t kSampleOffset16[4][2] = {{6, 2}, {14, 6}, {2, 10}, {10, 14}};
+    std::vector<std::atomic<uint64_t>> vis(P * S);
+    for (size_t k = 0; k < P * S; ++k) vis[k].store(CLEAR_KEY, std::memory_order_relaxed);
+    for (uint32_t smp = 0; smp < S; ++smp) {
+    const int32_t sub_dx = S == 1 ? 0 : SUB / 2 - kSampleOffset16[smp][0] * (SUB / 16);
+    const int32_t sub_dy = S == 1 ? 0 : SUB / 2 - kSampleOffset16[smp][1] * (SUB / 16);
     for (const DrawItem& it : items) {
         float bc[4];
         base_color(c, it.mat, nullptr, bc);     // texel alpha <= 1: below 0.5 here means below 0.5 for every fragment
@@ -715,13 +726,14 @@ static int render(Ctx& c) {
                                         sample_texture(*alpha_tex, f, texel);
                                         if (it.mat.base[3] * texel[3] < 0.5f) return;
                                     }
-                                    atomic_min(vis[(size_t)j * W + i], ((uint64_t)fbits(z) << 32) | id);
-                                });
+                                    atomic_min(vis[(size_t)smp * P + (size_t)j * W + i], ((uint64_t)fbits(z) << 32) | id);
+                                }, sub_dx, sub_dy);
             }
         });
     }
-    c.vis.resize(P);
-    for (size_t k = 0; k < P; ++k) c.vis[k] = vis[k].load(std::memory_order_relaxed);
+    }
+    c.vis.resize(P * S);        // read-backs show sample 0
+    for (size_t k = 0; k < P * S; ++k) c.vis[k] = vis[k].load(std::memory_order_relaxed);
 
     // K4: shading
     c.hdr.assign(P * 3, 0.0f);
@@ -733,46 +745,65 @@ static int render(Ctx& c) {
         size_t k = std::upper_bound(tri_bases.begin(), tri_bases.end(), id) - tri_bases.begin();
         return k - 1;
     };
+    if (c.mode != 0 && S != 1) { c.err = "the forward restatement covers sample count 1 only"; return RND_ERR_UNSUPPORTED; }
     if (c.mode != 0)
         for (const DrawItem& it : items)
             if (it.mat.texture != RND_NONE) { c.err = "the forward restatement covers untextured materials only"; return RND_ERR_UNSUPPORTED; }
     if (c.mode == 0) {
+        // colour of the fragment of triangle `id` at pixel (i, j), before the f16 store
+        auto shade = [&](uint32_t id, uint32_t i, uint32_t j) {
+            const DrawItem& it = items[item_of(id)];
+            uint32_t t = id - it.tri_base;
+            const Submesh& s = *it.sub;
+            float b[3], dbx[3], dby[3];
+            barycentrics(it.clip[s.idx[3 * t]], it.clip[s.idx[3 * t + 1]], it.clip[s.idx[3 * t + 2]], i, j, W, H, b, dbx, dby);
+            Frag f = frag_deferred(it, c.cam, t, b);
+            {   // screen-space uv derivatives for the mip level, analytic from the barycentrics'
+                const Vertex& va = s.verts[s.idx[3 * t]], &vb = s.verts[s.idx[3 * t + 1]], &vc = s.verts[s.idx[3 * t + 2]];
+                f.dudx = (dbx[0] * va.u + dbx[1] * vb.u) + dbx[2] * vc.u; f.dvdx = (dbx[0] * va.v + dbx[1] * vb.v) + dbx[2] * vc.v;
+                f.dudy = (dby[0] * va.u + dby[1] * vb.u) + dby[2] * vc.u; f.dvdy = (dby[0] * va.v + dby[1] * vb.v) + dby[2] * vc.v;
+            }
+            float bc[4];
+            base_color(c, it.mat, &f, bc);
+            V3 base{bc[0], bc[1], bc[2]};
+            V3 col = base;
+            if (!it.mat.unlit) {
+                // compute_ambient_light: base * (light_color * intensity)
+                V3 amb = V3{c.ambient[0], c.ambient[1], c.ambient[2]} * c.ambient[3];
+                col = base * amb;
+                for (const Light& l : c.lights) {
+                    V3 contrib;
+                    if (light_contribution(c, l, f, base, contrib)) col = col + contrib;
+                }
+            }
+            return col;
+        };
         parallel_for(c.threads, H, [&](size_t lo, size_t hi) {
             for (size_t j = lo; j < hi; ++j)
                 for (uint32_t i = 0; i < W; ++i) {
                     size_t p = j * W + i;
                     float* hdr = &c.hdr[p * 3];
-                    uint32_t id = (uint32_t)(c.vis[p] & 0xFFFFFFFFull);
-                    if (id == RND_NONE) {
-                        hdr[0] = clear[0]; hdr[1] = clear[1]; hdr[2] = clear[2];
-                    } else {
-                        const DrawItem& it = items[item_of(id)];
-                        uint32_t t = id - it.tri_base;
-                        const Submesh& s = *it.sub;
-                        float b[3], dbx[3], dby[3];
-                        barycentrics(it.clip[s.idx[3 * t]], it.clip[s.idx[3 * t + 1]], it.clip[s.idx[3 * t + 2]],
-                                     i, (uint32_t)j, W, H, b, dbx, dby);
-                        Frag f = frag_deferred(it, c.cam, t, b);
-                        {   // screen-space uv derivatives for the mip level, analytic from the barycentrics'
-                            const Vertex& va = s.verts[s.idx[3 * t]], &vb = s.verts[s.idx[3 * t + 1]], &vc = s.verts[s.idx[3 * t + 2]];
-                            f.dudx = (dbx[0] * va.u + dbx[1] * vb.u) + dbx[2] * vc.u; f.dvdx = (dbx[0] * va.v + dbx[1] * vb.v) + dbx[2] * vc.v;
-                            f.dudy = (dby[0] * va.u + dby[1] * vb.u) + dby[2] * vc.u; f.dvdy = (dby[0] * va.v + dby[1] * vb.v) + dby[2] * vc.v;
-                        }
-                        float bc[4];
-                        base_color(c, it.mat, &f, bc);
-                        V3 base{bc[0], bc[1], bc[2]};
-                        V3 col = base;
-                        if (!it.mat.unlit) {
-                            // compute_ambient_light: base * (light_color * intensity)
-                            V3 amb = V3{c.ambient[0], c.ambient[1], c.ambient[2]} * c.ambient[3];
-                            col = base * amb;
-                            for (const Light& l : c.lights) {
-                                V3 contrib;
-                                if (light_contribution(c, l, f, base, contrib)) col = col + contrib;
-                            }
-                        }
+                    if (S == 1) {
+                        uint32_t id = (uint32_t)(c.vis[p] & 0xFFFFFFFFull);
+                        if (id == RND_NONE) { hdr[0] = clear[0]; hdr[1] = clear[1]; hdr[2] = clear[2]; continue; }
+                        V3 col = shade(id, i, (uint32_t)j);
                         hdr[0] = round_f16(col.x); hdr[1] = round_f16(col.y); hdr[2] = round_f16(col.z);
+                        continue;
                     }
+                    // every sample holds the f16 colour of its winner (or the clear colour); the resolve
+                    // target gets their mean (resolve attachment, visual_server.rs:1134-1153)
+                    float sum[3] = {0, 0, 0};
+                    uint32_t last_id = RND_NONE; V3 last{0, 0, 0};
+                    for (uint32_t smp = 0; smp < S; ++smp) {
+                        uint32_t id = (uint32_t)(c.vis[(size_t)smp * P + p] & 0xFFFFFFFFull);
+                        float sc[3] = {clear[0], clear[1], clear[2]};
+                        if (id != RND_NONE) {
+                            if (id != last_id) { last = shade(id, i, (uint32_t)j); last_id = id; }
+                            sc[0] = round_f16(last.x); sc[1] = round_f16(last.y); sc[2] = round_f16(last.z);
+                        }
+                        for (int k = 0; k < 3; ++k) sum[k] = sum[k] + sc[k];
+                    }
+                    for (int k = 0; k < 3; ++k) hdr[k] = round_f16(sum[k] * 0.25f);
                 }
         });
     } else {
@@ -909,7 +940,8 @@ int orc_render_size_factor(const rnd_ctx* ctx, float* f) { *f = CCTX(ctx)->size_
 int orc_set_render_size_factor(rnd_ctx* ctx, float f) { return orc_apply_size(CTX(ctx), CCTX(ctx)->SW, CCTX(ctx)->SH, f); }
 int orc_msaa_sample_count(const rnd_ctx* ctx, uint32_t* n) { *n = CCTX(ctx)->msaa; return RND_OK; }
 int orc_set_msaa(rnd_ctx* ctx, uint32_t n) {
-    if (n != 1) { CTX(ctx)->err = "MSAA != 1 not built yet (SURVEY §8f N4)"; return n == 4 ? RND_ERR_UNSUPPORTED : RND_ERR_INVALID; }
+    if (n != 1 && n != 4) { CTX(ctx)->err = "sample count must be 1 or 4"; return RND_ERR_INVALID; }
+    CTX(ctx)->msaa = n; CTX(ctx)->have_frame = false;
     return RND_OK;
 }
 int orc_tone_mapping(const rnd_ctx* ctx, uint32_t* m) { *m = CCTX(ctx)->tone; return RND_OK; }
@@ -1031,17 +1063,17 @@ int orc_read_color_rgba8(rnd_ctx* ctx, uint8_t* dst) { Ctx* c = CTX(ctx); NEED_F
 int orc_read_color_hdr(rnd_ctx* ctx, float* dst) { Ctx* c = CTX(ctx); NEED_FRAME(c); std::memcpy(dst, c->hdr.data(), c->hdr.size() * 4); return RND_OK; }
 int orc_read_depth(rnd_ctx* ctx, float* dst) {
     Ctx* c = CTX(ctx); NEED_FRAME(c);
-    for (size_t p = 0; p < c->vis.size(); ++p) dst[p] = orc::bitsf((uint32_t)(c->vis[p] >> 32));
+    for (size_t p = 0; p < (size_t)c->W * c->H; ++p) dst[p] = orc::bitsf((uint32_t)(c->vis[p] >> 32));
     return RND_OK;
 }
 int orc_read_coverage(rnd_ctx* ctx, uint8_t* dst) {
     Ctx* c = CTX(ctx); NEED_FRAME(c);
-    for (size_t p = 0; p < c->vis.size(); ++p) dst[p] = (uint32_t)(c->vis[p] & 0xFFFFFFFFull) != RND_NONE;
+    for (size_t p = 0; p < (size_t)c->W * c->H; ++p) dst[p] = (uint32_t)(c->vis[p] & 0xFFFFFFFFull) != RND_NONE;
     return RND_OK;
 }
 int orc_read_triangle_ids(rnd_ctx* ctx, uint32_t* dst) {
     Ctx* c = CTX(ctx); NEED_FRAME(c);
-    for (size_t p = 0; p < c->vis.size(); ++p) dst[p] = (uint32_t)(c->vis[p] & 0xFFFFFFFFull);
+    for (size_t p = 0; p < (size_t)c->W * c->H; ++p) dst[p] = (uint32_t)(c->vis[p] & 0xFFFFFFFFull);
     return RND_OK;
 }
 int orc_last_timings(rnd_ctx* ctx, rnd_timings* out) { *out = CTX(ctx)->timings; return RND_OK; }

@@ -107,7 +107,10 @@ struct FrameConst {
     uint32_t n_items, n_lights;
     uint32_t n_tris, n_verts;
     uint32_t rank, world;
-    uint32_t n_units, pad0;        // setup work units of the frame (chunks over all draw items)
+    uint32_t n_units;              // setup work units of the frame (chunks over all draw items)
+    uint32_t n_samples;            // 1, or 4 (MSAA): visibility planes of the frame
+    int32_t sub_dx, sub_dy;        // whole sub-pixel steps added to every snapped vertex: the sample this
+                                   // geometry pass resolves, moved onto the pixel centre (0 without MSAA)
     double ndc_step_x, ndc_step_y;   // 2/width, 2/height in f64 (pixel centre -> NDC at shade time)
     float ndc_step_xf, ndc_step_yf;  // the same in f32
 };

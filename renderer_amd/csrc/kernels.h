@@ -20,6 +20,7 @@ struct FrameBuffers {
     const ShadowSet* shadow_sets;   // indexed by GpuLight::shadow_index
     const TextureDesc* textures;    // indexed by DrawItem::texture
     uint32_t alpha_test;            // some draw item has kItemAlphaTest: launch the raster variants with the test
+    uint32_t has_textures;          // some draw item is textured: launch the full shading variant
     const uint32_t* unit_bases;     // n_items + 1: first work unit of each item
     uint2* active_units;            // (item, chunk) of the work units that survived k_cull
     uint32_t* vblock_needed;        // per kVertexBlock block of the frame's vertex slots: used by a surviving unit
@@ -37,7 +38,9 @@ struct FrameBuffers {
     // pixel stage
     const TileRef* launch_order;    // owned tiles in launch order (XCD-aware)
     uint32_t n_owned;
-    uint64_t* vis;                  // tile-major (depth bits << 32 | triangle id), 1024 per tile
+    uint64_t* vis;                  // tile-major (depth bits << 32 | triangle id), 1024 per tile; with MSAA the
+                                    // plane of the sample a geometry pass resolves / of sample 0 for shading
+    uint64_t vis_stride;            // words between the planes of consecutive samples
     uint8_t* frame_rgba8;           // row-major RGBA8 frame (may be null)
     uint8_t* tiles_rgba8;           // tile-major RGBA8 of owned tiles (may be null)
     uint64_t* packed;               // row-major (depth bits << 32 | rgba8) (may be null)

@@ -243,15 +243,18 @@ __global__ __launch_bounds__(256) void k_transform(const DrawItem* __restrict__ 
 // ------------------------------------------------------------------------------------------
 struct Snapped { int32_t x, y; float z; };
 
+// (sub_dx, sub_dy): whole sub-pixel steps added after the snap.  With MSAA, sample k of a pixel at
+// offset (ox, oy) from the pixel's corner is the pixel centre of the geometry moved by
+// (1/2 - ox, 1/2 - oy); the offsets of the 4x pattern are multiples of 1/16 px, exact on the grid.
 __device__ __forceinline__ bool snap_vertex(float cx, float cy, float cz, float cw, float half_w,
-                                            float half_h, Snapped& s) {
+                                            float half_h, Snapped& s, int32_t sub_dx, int32_t sub_dy) {
     if (!(cw > 0.0f)) return false;
     float rw = 1.0f / cw;
     float nx = cx * rw, ny = cy * rw, nz = cz * rw;
     float sx = (nx + 1.0f) * half_w;
     float sy = (1.0f - ny) * half_h;
-    s.x = (int32_t)rintf(sx * (float)kSub);
-    s.y = (int32_t)rintf(sy * (float)kSub);
+    s.x = (int32_t)rintf(sx * (float)kSub) + sub_dx;
+    s.y = (int32_t)rintf(sy * (float)kSub) + sub_dy;
     s.z = nz;
     return true;
 }
@@ -514,9 +517,9 @@ __device__ __forceinline__ void setup_triangle(const float4& c0, const float4& c
                 fminf(fminf(c0.y + g0, c1.y + g1), c2.y + g2) < 0.0f || fminf(fminf(g0 - c0.y, g1 - c1.y), g2 - c2.y) < 0.0f;
     if (need_clip) return;
     Snapped s0, s1, s2;
-    bool ok0 = snap_vertex(c0.x, c0.y, c0.z, c0.w, half_w, half_h, s0);
-    bool ok1 = snap_vertex(c1.x, c1.y, c1.z, c1.w, half_w, half_h, s1);
-    bool ok2 = snap_vertex(c2.x, c2.y, c2.z, c2.w, half_w, half_h, s2);
+    bool ok0 = snap_vertex(c0.x, c0.y, c0.z, c0.w, half_w, half_h, s0, fc.sub_dx, fc.sub_dy);
+    bool ok1 = snap_vertex(c1.x, c1.y, c1.z, c1.w, half_w, half_h, s1, fc.sub_dx, fc.sub_dy);
+    bool ok2 = snap_vertex(c2.x, c2.y, c2.z, c2.w, half_w, half_h, s2, fc.sub_dx, fc.sub_dy);
     if (ok0 && ok1 && ok2) emit = make_record(s0, s1, s2, gid, fc, rec, tr) && any_owned(tr, fc);
 }
 
@@ -766,7 +769,7 @@ __global__ __launch_bounds__(256) void k_clip(FrameBuffers fb, FrameConst fc, Ca
         float half_w = 0.5f * (float)fc.width, half_h = 0.5f * (float)fc.height;
         Snapped s[12];
         bool ok = true;
-        for (int k = 0; k < cnt; ++k) { bool o = snap_vertex(a[k].x, a[k].y, a[k].z, a[k].w, half_w, half_h, s[k]); ok = ok && o; }
+        for (int k = 0; k < cnt; ++k) { bool o = snap_vertex(a[k].x, a[k].y, a[k].z, a[k].w, half_w, half_h, s[k], fc.sub_dx, fc.sub_dy); ok = ok && o; }
         if (!ok) continue;
         for (int k = 1; k + 1 < cnt; ++k) {
             SetupRecord rec;
@@ -1079,6 +1082,7 @@ struct PixelInputs {
 // vs_main outputs re-derived for the winning triangle of one pixel, and the ambient term.
 // `d` is wave-uniform (the caller waterfalls over the items of the wave), so its fields come in
 // through scalar loads; per pixel only the index triple and the three 32-byte vertices are gathered.
+template <bool kTextures>
 __device__ __forceinline__ void prepare_pixel(const DrawItem& d, const FrameConst& fc, const float4* __restrict__ clip,
                                               const TextureDesc* __restrict__ textures, uint32_t id, uint32_t i,
                                               uint32_t j, PixelInputs& o, FrameCounters* counters) {
@@ -1151,7 +1155,7 @@ __device__ __forceinline__ void prepare_pixel(const DrawItem& d, const FrameCons
     // base colour = material.base_color * textureSample(...) (render_mesh.wgsl:89, :142); untextured
     // materials bind the 1x1 white texture (visual_server.rs:736)
     float tr = 1.0f, tg = 1.0f, tb = 1.0f;
-    if (d.texture != RND_NONE) {        // uniform over the wave (d is)
+    if (kTextures && d.texture != RND_NONE) {        // uniform over the wave (d is)
         const float u0 = a1.z, v0 = a1.w, u1 = b1v.z, v1 = b1v.w, u2 = c1v.z, v2 = c1v.w;
         const float uu = (b0 * u0 + b1 * u1) + b2 * u2, vv = (b0 * v0 + b1 * v1) + b2 * v2;
         // screen-space uv derivatives for the mip level, analytic: the edge functions are affine in
@@ -1337,10 +1341,15 @@ __device__ __forceinline__ void add_light_pair(const GpuLight& L, PixelPair& p, 
 #endif
 
 // PPT pixels per lane: a workgroup shades 256*PPT consecutive pixels (8*PPT rows) of one tile.
-// kShadows: the frame has directional lights with cascade sets (the lookup costs registers, so
-// frames without them run the variant compiled without it).
-template <int PPT, bool kShadows>
+// kShadows ("full" variant): the frame has directional lights with cascade sets or textured draw
+// items; both cost registers, so frames without them run the variant compiled without them.
+// kSamples: 1, or 4 (MSAA, PPT 1): phases A-C run once per sample plane — the fragment of the sample's
+// winning triangle is shaded at the pixel centre, exactly as the reference's per-pixel fragment stage,
+// and re-used while consecutive samples hold the same triangle — each sample keeps the f16 colour,
+// and the pixel gets their mean (the resolve attachment, visual_server.rs:1134-1153).
+template <int PPT, bool kShadows, int kSamples>
 __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(FrameBuffers fb, FrameConst fc) {
+    static_assert(kSamples == 1 || PPT == 1, "the MSAA variant shades one pixel per lane");
     __shared__ GpuLight s_lights[kMaxLights];
     __shared__ uint32_t s_bases[kLdsItems + 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -1356,24 +1365,39 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(
     const TileRef ref = fb.launch_order[blockIdx.x % fb.n_owned];
     const uint32_t part = (blockIdx.x / fb.n_owned) * (256u * PPT);     // first tile-local pixel of this workgroup
     const uint32_t tile_x0 = (ref.tile % fc.tiles_x) * kTile, tile_y0 = (ref.tile / fc.tiles_x) * kTile;
-    const unsigned long long* vis = reinterpret_cast<const unsigned long long*>(fb.vis) + (size_t)ref.tile * kTilePixels;
+    const unsigned long long* vis0 = reinterpret_cast<const unsigned long long*>(fb.vis) + (size_t)ref.tile * kTilePixels;
     __syncthreads();
 
-    // phase A: fragment inputs of this lane's four pixels
     PixelInputs px[PPT];
     unsigned long long key[PPT];
     bool covered[PPT];
+    float sum_r = 0.0f, sum_g = 0.0f, sum_b = 0.0f;     // MSAA: running sum of the samples' f16 colours
+    uint32_t prev_id = RND_NONE;
+    unsigned long long key0 = 0;
+  for (int smp = 0; smp < kSamples; ++smp) {
+    const unsigned long long* vis = vis0 + (size_t)smp * fb.vis_stride;
+    // phase A: fragment inputs of this lane's pixels
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    bool reuse = false;
 #pragma unroll
     for (uint32_t k = 0; k < PPT; ++k) {
         uint32_t local = part + wave * (64u * PPT) + k * 64u + lane;      // a wave holds 2*PPT consecutive rows
         uint32_t i = tile_x0 + (local & (kTile - 1)), j = tile_y0 + (local / kTile);
         key[k] = vis[local];
         uint32_t id = (uint32_t)(key[k] & 0xFFFFFFFFull);
+        if constexpr (kSamples > 1) {
+            if (smp == 0) key0 = key[k];
+            // same triangle as the previous sample: same fragment, same colour (px[k] still holds it)
+            reuse = smp > 0 && id == prev_id;
+            prev_id = id;
+        }
         covered[k] = i < fc.width && j < fc.height && id != RND_NONE;
+        if constexpr (kSamples > 1) covered[k] = covered[k] && !reuse;
         if (covered[k] && !guard(id < fc.n_tris, fb.counters, kGuardShade)) covered[k] = false;
-        px[k] = PixelInputs{};
-        px[k].cr = fc.clear_hdr[0]; px[k].cg = fc.clear_hdr[1]; px[k].cb = fc.clear_hdr[2];
+        if (kSamples == 1 || !reuse) {
+            px[k] = PixelInputs{};
+            px[k].cr = fc.clear_hdr[0]; px[k].cg = fc.clear_hdr[1]; px[k].cb = fc.clear_hdr[2];
+        }
         uint32_t it = 0;
         if (covered[k]) it = bases_in_lds ? find_item(s_bases, fc.n_items, id) : find_item(fb.tri_bases, fc.n_items, id);
         const unsigned long long cov = __ballot(covered[k]);
@@ -1383,7 +1407,7 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(
             if (__ballot(covered[k] && it != lead) == 0ull) {
                 // the usual case: every covered pixel of the wave belongs to one draw item
                 const DrawItem d = load_item_uniform(fb.items, lead_s);
-                if (covered[k]) prepare_pixel(d, fc, fb.clip, fb.textures, id, i, j, px[k], fb.counters);
+                if (covered[k]) prepare_pixel<kShadows>(d, fc, fb.clip, fb.textures, id, i, j, px[k], fb.counters);
             } else if (covered[k]) {
                 // waterfall: one pass per distinct draw item among the wave's pixels
                 for (unsigned long long pending = __ballot(true); pending;) {
@@ -1392,7 +1416,7 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(
                     pending &= ~__ballot(mine);
                     if (mine) {
                         const DrawItem d = load_item_uniform(fb.items, cur_s);
-                        prepare_pixel(d, fc, fb.clip, fb.textures, id, i, j, px[k], fb.counters);
+                        prepare_pixel<kShadows>(d, fc, fb.clip, fb.textures, id, i, j, px[k], fb.counters);
                     }
                 }
             }
@@ -1448,7 +1472,7 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(
 #endif
 #pragma unroll
                 for (uint32_t k = 0; k < PPT; ++k)
-                    if (px[k].lit) add_light<kShadows>(L, px[k], fb.shadow_sets, fc);
+                    if (px[k].lit && (kSamples == 1 || covered[k])) add_light<kShadows>(L, px[k], fb.shadow_sets, fc);
             }
         }
     }
@@ -1458,6 +1482,14 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(
         px[1].cr = pp.cr.y; px[1].cg = pp.cg.y; px[1].cb = pp.cb.y;
     }
 #endif
+    if constexpr (kSamples > 1) {
+        sum_r = sum_r + round_f16(px[0].cr); sum_g = sum_g + round_f16(px[0].cg); sum_b = sum_b + round_f16(px[0].cb);
+    }
+  }
+    if constexpr (kSamples > 1) {
+        px[0].cr = sum_r * 0.25f; px[0].cg = sum_g * 0.25f; px[0].cb = sum_b * 0.25f;
+        key[0] = key0;      // the packed frame carries sample 0's depth
+    }
     // phase D: f16 target, tone map, sRGB (show_texture.wgsl + the sRGB surface)
 #pragma unroll
     for (uint32_t k = 0; k < PPT; ++k) {
@@ -1607,16 +1639,19 @@ void launch_raster(const FrameBuffers& fb, const FrameConst& fc, const Capacitie
 void launch_shade(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream) {
     if (!fb.n_owned) return;
     static const int ppt = [] { const char* e = getenv("RND_SHADE_PPT"); int v = e ? atoi(e) : 2; return (v == 1 || v == 2 || v == 4) ? v : 1; }();
-    const bool sh = fb.shadow_sets != nullptr;
-    if (ppt == 4) {
-        if (sh) hipLaunchKernelGGL((k_shade<4, true>), dim3(fb.n_owned), dim3(256), 0, stream, fb, fc);
-        else hipLaunchKernelGGL((k_shade<4, false>), dim3(fb.n_owned), dim3(256), 0, stream, fb, fc);
+    const bool sh = fb.shadow_sets != nullptr || fb.has_textures;
+    if (fc.n_samples == 4) {
+        if (sh) hipLaunchKernelGGL((k_shade<1, true, 4>), dim3(fb.n_owned * 4), dim3(256), 0, stream, fb, fc);
+        else hipLaunchKernelGGL((k_shade<1, false, 4>), dim3(fb.n_owned * 4), dim3(256), 0, stream, fb, fc);
+    } else if (ppt == 4) {
+        if (sh) hipLaunchKernelGGL((k_shade<4, true, 1>), dim3(fb.n_owned), dim3(256), 0, stream, fb, fc);
+        else hipLaunchKernelGGL((k_shade<4, false, 1>), dim3(fb.n_owned), dim3(256), 0, stream, fb, fc);
     } else if (ppt == 2) {
-        if (sh) hipLaunchKernelGGL((k_shade<2, true>), dim3(fb.n_owned * 2), dim3(256), 0, stream, fb, fc);
-        else hipLaunchKernelGGL((k_shade<2, false>), dim3(fb.n_owned * 2), dim3(256), 0, stream, fb, fc);
+        if (sh) hipLaunchKernelGGL((k_shade<2, true, 1>), dim3(fb.n_owned * 2), dim3(256), 0, stream, fb, fc);
+        else hipLaunchKernelGGL((k_shade<2, false, 1>), dim3(fb.n_owned * 2), dim3(256), 0, stream, fb, fc);
     } else {
-        if (sh) hipLaunchKernelGGL((k_shade<1, true>), dim3(fb.n_owned * 4), dim3(256), 0, stream, fb, fc);
-        else hipLaunchKernelGGL((k_shade<1, false>), dim3(fb.n_owned * 4), dim3(256), 0, stream, fb, fc);
+        if (sh) hipLaunchKernelGGL((k_shade<1, true, 1>), dim3(fb.n_owned * 4), dim3(256), 0, stream, fb, fc);
+        else hipLaunchKernelGGL((k_shade<1, false, 1>), dim3(fb.n_owned * 4), dim3(256), 0, stream, fb, fc);
     }
 }
 void launch_extract(const uint64_t* vis, const TileRef* order, uint32_t n_owned, const FrameConst& fc, float* depth,

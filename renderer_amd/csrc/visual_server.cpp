@@ -113,9 +113,12 @@ void VisualServer::apply_size(uint32_t sw, uint32_t sh, float f) {
 void VisualServer::set_render_size(uint32_t w, uint32_t h) { apply_size(w, h, render_size_factor_); }
 void VisualServer::set_render_size_factor(float f) { apply_size(surface_w_, surface_h_, f); }
 void VisualServer::set_msaa(uint32_t n) {
-    if (n == 1) { msaa_ = 1; return; }
-    if (n == 4) throw Error(RND_ERR_UNSUPPORTED, "MSAA 4 not built yet (SURVEY §8f N4)");
-    throw Error(RND_ERR_INVALID, "sample count must be 1 or 4");
+    if (n != 1 && n != 4) throw Error(RND_ERR_INVALID, "sample count must be 1 or 4");
+    if (n == msaa_) return;
+    finish();
+    msaa_ = n;
+    have_frame_ = false;
+    rebuild_tiles();    // recreate_render_targets (visual_server.rs:178-181): one visibility plane per sample
 }
 void VisualServer::set_tone_mapping(uint32_t m) {
     if (m > 1) throw Error(RND_ERR_INVALID, "tone mapping must be 0 (None) or 1 (Reinhard)");
@@ -150,7 +153,7 @@ void VisualServer::rebuild_tiles() {
     if (n_owned_) HIP_CHECK(hipMemcpy(d_launch_order_.ptr, order.data(), n_owned_ * sizeof(TileRef), hipMemcpyHostToDevice));
     const size_t n_tiles = (size_t)tiles_x_ * tiles_y_;
     d_tile_count_.ensure(2 * n_tiles); d_tile_offset_.ensure(n_tiles); d_tile_cursor_.ensure(n_tiles);
-    d_vis_.ensure(n_tiles * kTilePixels);
+    d_vis_.ensure(n_tiles * kTilePixels * msaa_);
     d_frame_.ensure((size_t)width_ * height_ * 4);
     if (world_ > 1) d_tiles_.ensure(std::max<size_t>((size_t)n_owned_ * kTilePixels * 4, 4));
 }
@@ -341,7 +344,7 @@ void VisualServer::build_frame(std::vector<DrawItem>& items, std::vector<uint32_
                                std::vector<GpuLight>& lights, std::vector<DrawItem>& shadow_items) {
     const Mat4 pv = projection_ * view_;
     uint64_t vert_base = 0, tri_base = 0, unit_base = 0;
-    frame_alpha_test_ = false;
+    frame_alpha_test_ = false; frame_textured_ = false;
     // for mesh_instance { for submesh } — visual_server.rs:227-245
     for (const RenderMeshInstance& inst : mesh_instances_) {
         const RenderMesh& mesh = meshes_.at(inst.mesh);
@@ -381,6 +384,7 @@ void VisualServer::build_frame(std::vector<DrawItem>& items, std::vector<uint32_
                 auto tex = textures_.find(mat.texture);
                 if (tex == textures_.end()) throw Error(RND_ERR_UNKNOWN_ID, "texture id not registered");
                 d.texture = tex->second.slot;
+                frame_textured_ = true;
                 if (!tex->second.opaque && !(d.flags & kItemSkip)) { d.flags |= kItemAlphaTest; frame_alpha_test_ = true; }
             }
             d.chunks = s.chunks.ptr; d.n_chunks = s.n_chunks; d.unit_base = (uint32_t)unit_base;
@@ -426,9 +430,20 @@ void VisualServer::build_frame(std::vector<DrawItem>& items, std::vector<uint32_
     fc.rank = rank_; fc.world = world_;
     fc.ndc_step_x = 2.0 / (double)width_; fc.ndc_step_y = 2.0 / (double)height_;
     fc.ndc_step_xf = (float)fc.ndc_step_x; fc.ndc_step_yf = (float)fc.ndc_step_y;
+    fc.n_samples = msaa_;
+    fc.sub_dx = fc.sub_dy = 0;
+    if (msaa_ > 1) sample_shift(0, fc.sub_dx, fc.sub_dy);
 }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// The standard 4x sample pattern, offsets from the pixel corner in 1/16 px; the shift that puts sample
+// `smp` on the pixel centre, in sub-pixel steps.
+void VisualServer::sample_shift(uint32_t smp, int32_t& dx, int32_t& dy) {
+    static const int32_t k16[4][2] = {{6, 2}, {14, 6}, {2, 10}, {10, 14}};
+    dx = kSub / 2 - k16[smp & 3][0] * (kSub / 16);
+    dy = kSub / 2 - k16[smp & 3][1] * (kSub / 16);
+}
 
 void VisualServer::enqueue_frame(bool want_hdr) {
     use_device();
@@ -467,7 +482,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
         const size_t need = std::max<size_t>((size_t)tiles_x_ * tiles_y_, kShadowTiles);
         d_tile_count_.ensure(2 * need); d_tile_offset_.ensure(need); d_tile_cursor_.ensure(need);
     }
-    n_counter_sets_ = 1 + n_passes;
+    n_counter_sets_ = 1 + n_passes + (msaa_ - 1);
     d_counters_.ensure(n_counter_sets_);
     if (h_counter_sets_ < n_counter_sets_) {
         if (frame_pending_) HIP_CHECK(hipStreamSynchronize(stream_));
@@ -543,6 +558,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     fb.items = d_items_.ptr; fb.vert_bases = d_vert_bases_.ptr; fb.tri_bases = d_tri_bases_.ptr; fb.lights = d_lights_.ptr;
     fb.textures = d_textures_.ptr;
     fb.alpha_test = frame_alpha_test_ ? 1u : 0u;
+    fb.has_textures = frame_textured_ ? 1u : 0u;
     fb.shadow_sets = n_sets ? d_shadow_sets_.ptr : nullptr;      // null selects the shading kernel without the lookup
     fb.clip = d_clip_.ptr; fb.records = d_records_.ptr; fb.tilewords = reinterpret_cast<uint2*>(d_tilewords_.ptr); fb.clip_queue = d_clip_queue_.ptr;
     fb.chunk_count = d_chunk_count_.ptr;
@@ -551,6 +567,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     fb.entries = d_entries_.ptr; fb.counters = d_counters_.ptr;
     fb.launch_order = d_launch_order_.ptr; fb.n_owned = n_owned_;
     fb.vis = d_vis_.ptr;
+    fb.vis_stride = (uint64_t)tiles_x_ * tiles_y_ * kTilePixels;
     fb.frame_rgba8 = (world_ > 1 || scaled()) ? nullptr : d_frame_.ptr;
     fb.tiles_rgba8 = world_ > 1 ? (ext_tiles_ ? ext_tiles_ : d_tiles_.ptr) : nullptr;
     fb.packed = want_packed_ ? d_packed_.ptr : nullptr;
@@ -576,6 +593,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
             lights_[shadowed[k]].cascades[c].to_cols_array(sfc.pv);
             sfc.width = sfc.height = kShadowSize; sfc.tiles_x = sfc.tiles_y = kShadowSize / kTile;
             sfc.rank = 0; sfc.world = 1; sfc.n_lights = 0;
+            sfc.n_samples = 1; sfc.sub_dx = sfc.sub_dy = 0;      // shadow maps are single-sampled (visual_server.rs:371)
             launch_clear(sfb, sfc, stream_);
             launch_cull(sfb, sfc, stream_);
             launch_transform(sfb, sfc, stream_);
@@ -598,6 +616,22 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     launch_bin(fb, fc, cap_, stream_);
     HIP_CHECK(hipEventRecord(ev_[4], stream_));
     launch_raster(fb, fc, cap_, stream_);
+    // MSAA: the other samples' visibility planes, one more geometry pass each with the snapped
+    // vertices moved so that the sample sits on the pixel centre (clip positions are shared)
+    for (uint32_t smp = 1; smp < msaa_; ++smp) {
+        FrameBuffers mfb = fb;
+        mfb.vis = d_vis_.ptr + (size_t)smp * fb.vis_stride;
+        mfb.counters = d_counters_.ptr + 1 + n_passes + (smp - 1);
+        FrameConst mfc = fc;
+        sample_shift(smp, mfc.sub_dx, mfc.sub_dy);
+        launch_clear(mfb, mfc, stream_);
+        launch_cull(mfb, mfc, stream_);
+        launch_setup(mfb, mfc, cap_, stream_);
+        launch_clip(mfb, mfc, cap_, stream_);
+        launch_scan(mfb, mfc, cap_, stream_);
+        launch_bin(mfb, mfc, cap_, stream_);
+        launch_raster(mfb, mfc, cap_, stream_);
+    }
     HIP_CHECK(hipEventRecord(ev_[5], stream_));
     launch_shade(fb, fc, stream_);
     if (scaled())   // show_texture.wgsl over the surface (visual_server.rs:629-633: filtered sampler above factor 1)

@@ -30,7 +30,7 @@ def render_pair(scene: SceneDesc, tone=1, materials=None):
     return out
 
 
-def assert_parity(gpu, cpu, min_covered=1, hdr=True, shadow_taps=False):
+def assert_parity(gpu, cpu, min_covered=1, hdr=True, shadow_taps=False, hdr_tol=2 ** -10):
     cov_g, cov_c = gpu.read_coverage(), cpu.read_coverage()
     assert cov_c.sum() >= min_covered
     assert (cov_g == cov_c).all(), f"coverage differs on {(cov_g != cov_c).sum()} pixels"
@@ -56,7 +56,7 @@ def assert_parity(gpu, cpu, min_covered=1, hdr=True, shadow_taps=False):
             rel = rel[~flips]
         # the light loop uses v_rcp/v_rsq (1 ulp): the f32 sums differ in the last bits, which can move
         # a value across an f16 rounding boundary: at most one f16 ulp, on a small share of values
-        assert rel.max() <= 2 ** -10, f"HDR differs, max rel {rel.max()}"
+        assert rel.max() <= hdr_tol, f"HDR differs, max rel {rel.max()}"
         assert (rel > 0).mean() < 2e-2, (rel > 0).mean()
     return diff
 
@@ -316,3 +316,40 @@ def test_cutout_texture_alpha_test_and_sprites():
     assert_parity(gpu, cpu, min_covered=10000, hdr=False)
     cov = cpu.read_coverage()
     assert 0.1 < cov.mean() < 0.9          # the cut-outs really cut
+
+
+def test_msaa4():
+    """N4: sample count 4 — per-sample coverage and depth at the standard pattern, one shading per pixel
+    and triangle, resolve = mean of the samples' f16 colours."""
+    s = soup_scene(41, 220, 140, n_meshes=3, n_tri=70, lights=3)
+    pair = []
+    for make in (lambda: VisualServer(s.width, s.height, device=0), lambda: oracle_server(s.width, s.height)):
+        vs = make()
+        vs.set_msaa(4)
+        s.populate(vs)
+        vs.render()
+        pair.append(vs)
+    gpu, cpu = pair
+    assert gpu.msaa_sample_count() == 4
+    assert_parity(gpu, cpu, min_covered=3000, shadow_taps=True, hdr_tol=2 ** -9)       # integer planes: sample 0; HDR: an f16 ulp per sample, averaged, rounded once more
+    # edges are really blended: colours that neither the single-sample frame nor the clear colour hold
+    one = oracle_server(s.width, s.height)
+    s.populate(one)
+    one.render()
+    a, b = cpu.read_color_rgba8().astype(int), one.read_color_rgba8().astype(int)
+    assert 0.01 < (np.abs(a - b).max(axis=-1) > 2).mean() < 0.5
+    # C2-like micro-triangles: every pixel has several triangles among its samples
+    g = c2_grid_1m(width=320, height=180, scale=0.2)
+    pair = []
+    for make in (lambda: VisualServer(g.width, g.height, device=0), lambda: oracle_server(g.width, g.height)):
+        vs = make()
+        vs.set_msaa(4)
+        g.populate(vs)
+        vs.render()
+        pair.append(vs)
+    assert_parity(pair[0], pair[1], min_covered=320 * 180 // 2, hdr_tol=2 ** -9)
+    # and back to one sample
+    for vs in pair:
+        vs.set_msaa(1)
+        vs.render()
+    assert_parity(pair[0], pair[1], min_covered=320 * 180 // 2)

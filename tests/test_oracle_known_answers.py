@@ -508,3 +508,33 @@ def test_ka16_render_size_factor(factor):
     assert np.abs(out[..., :3].astype(int) - want).max() <= 1
     assert (out[..., 3] == 255).all()
     assert (vs.read_coverage().sum() > 50 * factor * factor)
+
+
+# ---- KA17: MSAA x4 ---------------------------------------------------------
+
+def test_ka17_msaa4_edge_coverage_fractions():
+    """Sample count 4 (visual_server.rs:174-181): coverage per sample at the standard pattern
+    (6,2) (14,6) (2,10) (10,14) /16, one shading per pixel, resolve = mean of the samples.  A unlit
+    white half-plane whose vertical edge cuts pixel columns at x = k + f covers the samples with
+    offset.x > f: the resolved value steps through 4/4, 3/4, 2/4, 1/4, 0/4 of white over the clear
+    colour."""
+    w, h = 32, 8
+    vs = oracle_server(w, h, threads=1)
+    cam = Camera(aspect_ratio=w / h)
+    vs.set_camera(identity(), cam)
+    vs.set_tone_mapping(0)
+    vs.set_msaa(4)
+    assert vs.msaa_sample_count() == 4
+    mat = vs.asset_server.add(Material(base_color=Color(1, 1, 1, 1), unlit=True))
+    clear = np.float32([np.float16(0.02), np.float16(0.04), np.float16(0.08)])
+    for edge, n_cov in ((10.0, 4), (10.25, 3), (10.5, 2), (10.75, 1), (10.9, 0)):
+        # the half-plane x >= edge, as one big triangle pair spanning the rows
+        pts = [(edge, -4), (edge, h + 4), (w + 8, -4), (w + 8, h + 4)]
+        pos = [screen_to_view(x, y, 2.0, w, h, cam) for x, y in pts]
+        mesh = vs.asset_server.add(Mesh([Submesh(make_vertices(pos), np.array([0, 1, 2, 2, 1, 3], dtype=np.uint32), mat)]))
+        vs.set_mesh_instance(1, identity(), mesh)
+        vs.render()
+        hdr = vs.read_color_hdr()
+        want = np.float16((n_cov * np.float32(1.0) + (4 - n_cov) * clear) * np.float32(0.25)).astype(np.float32)
+        assert np.allclose(hdr[3, 10], want, rtol=0, atol=1e-6), (edge, hdr[3, 10], want)
+        assert np.allclose(hdr[3, 11], 1.0) and np.allclose(hdr[3, 9], clear)
