@@ -248,15 +248,16 @@ struct Snapped { int32_t x, y; float z; };
 // (1/2 - ox, 1/2 - oy); the offsets of the 4x pattern are multiples of 1/16 px, exact on the grid.
 __device__ __forceinline__ bool snap_vertex(float cx, float cy, float cz, float cw, float half_w,
                                             float half_h, Snapped& s, int32_t sub_dx, int32_t sub_dy) {
-    if (!(cw > 0.0f)) return false;
+    // straight-line; a vertex with w <= 0 yields defined garbage and false (callers drop the triangle).
+    // The clamp only matters for that garbage: inside the guard band |s * 256| stays below 2^26.
     float rw = 1.0f / cw;
     float nx = cx * rw, ny = cy * rw, nz = cz * rw;
     float sx = (nx + 1.0f) * half_w;
     float sy = (1.0f - ny) * half_h;
-    s.x = (int32_t)rintf(sx * (float)kSub) + sub_dx;
-    s.y = (int32_t)rintf(sy * (float)kSub) + sub_dy;
+    s.x = (int32_t)fminf(fmaxf(rintf(sx * (float)kSub), -1.0e9f), 1.0e9f) + sub_dx;
+    s.y = (int32_t)fminf(fmaxf(rintf(sy * (float)kSub), -1.0e9f), 1.0e9f) + sub_dy;
     s.z = nz;
-    return true;
+    return cw > 0.0f;
 }
 
 struct TileRect {
@@ -270,7 +271,8 @@ __device__ __forceinline__ bool make_record(const Snapped& a, const Snapped& b, 
                                             TileRect& tr) {
     long long A2 = (long long)(b.x - a.x) * (c.y - a.y) - (long long)(c.x - a.x) * (b.y - a.y);
     long long area2 = -A2;
-    if (area2 <= 0) return false;
+    // straight-line: everything is computed, the verdict is one predicate at the end (early returns
+    // here became nested branches that each re-initialized the caller's outputs)
     int32_t xmin = min(a.x, min(b.x, c.x)), xmax = max(a.x, max(b.x, c.x));
     int32_t ymin = min(a.y, min(b.y, c.y)), ymax = max(a.y, max(b.y, c.y));
     // pixel centres i*256+128 inside the closed bbox
@@ -278,7 +280,6 @@ __device__ __forceinline__ bool make_record(const Snapped& a, const Snapped& b, 
     int32_t i1 = min((xmax - kSub / 2) >> kSubpixelBits, (int32_t)fc.width - 1);
     int32_t j0 = max((ymin - kSub / 2 + kSub - 1) >> kSubpixelBits, 0);
     int32_t j1 = min((ymax - kSub / 2) >> kSubpixelBits, (int32_t)fc.height - 1);
-    if (i0 > i1 || j0 > j1) return false;
     r.x0 = a.x; r.y0 = a.y; r.x1 = b.x; r.y1 = b.y; r.x2 = c.x; r.y2 = c.y;
     r.z0 = a.z; r.dz1 = b.z - a.z; r.dz2 = c.z - a.z;
     r.inv_area = 1.0f / (float)area2;
@@ -287,7 +288,7 @@ __device__ __forceinline__ bool make_record(const Snapped& a, const Snapped& b, 
     tr.tx0 = (uint32_t)i0 / kTile; tr.tx1 = (uint32_t)i1 / kTile;
     tr.ty0 = (uint32_t)j0 / kTile; tr.ty1 = (uint32_t)j1 / kTile;
     tr.i0 = i0; tr.i1 = i1; tr.j0 = j0; tr.j1 = j1;
-    return true;
+    return area2 > 0 && i0 <= i1 && j0 <= j1;
 }
 
 __device__ __forceinline__ uint32_t pack_tileword(const TileRect& t) {
@@ -497,7 +498,6 @@ __device__ __forceinline__ void setup_triangle(const float4& c0, const float4& c
     bool finite = isfinite(c0.x) && isfinite(c0.y) && isfinite(c0.z) && isfinite(c0.w) &&
                   isfinite(c1.x) && isfinite(c1.y) && isfinite(c1.z) && isfinite(c1.w) &&
                   isfinite(c2.x) && isfinite(c2.y) && isfinite(c2.z) && isfinite(c2.w);
-    if (!finite) return;
     // Trivial reject against the view volume and the "needs the clipper" test.  For finite a, b the
     // rounded sum a + b has the sign of the exact sum (and is zero only if that is), so
     // x < -w  <=>  x + w < 0 and x > w  <=>  w - x < 0; "all three outside" is then a max3 below zero
@@ -507,20 +507,24 @@ __device__ __forceinline__ void setup_triangle(const float4& c0, const float4& c
     const float yl0 = c0.y + c0.w, yl1 = c1.y + c1.w, yl2 = c2.y + c2.w;
     const float yr0 = c0.w - c0.y, yr1 = c1.w - c1.y, yr2 = c2.w - c2.y;
     const float zf0 = c0.w - c0.z, zf1 = c1.w - c1.z, zf2 = c2.w - c2.z;      // >= 0 in front of the far plane
-    const bool out = fmaxf(fmaxf(xl0, xl1), xl2) < 0.0f || fmaxf(fmaxf(xr0, xr1), xr2) < 0.0f ||
-                     fmaxf(fmaxf(yl0, yl1), yl2) < 0.0f || fmaxf(fmaxf(yr0, yr1), yr2) < 0.0f ||
-                     fmaxf(fmaxf(c0.z, c1.z), c2.z) < 0.0f || fmaxf(fmaxf(zf0, zf1), zf2) < 0.0f;
-    if (out) return;
+    // The six per-plane results are folded with min before the one comparison: no short-circuit chain.
+    const float out_m = fminf(fminf(fminf(fmaxf(fmaxf(xl0, xl1), xl2), fmaxf(fmaxf(xr0, xr1), xr2)),
+                                    fminf(fmaxf(fmaxf(yl0, yl1), yl2), fmaxf(fmaxf(yr0, yr1), yr2))),
+                              fminf(fmaxf(fmaxf(c0.z, c1.z), c2.z), fmaxf(fmaxf(zf0, zf1), zf2)));
     const float g0 = kGuardBand * c0.w, g1 = kGuardBand * c1.w, g2 = kGuardBand * c2.w;
-    need_clip = fminf(fminf(c0.z, c1.z), c2.z) < 0.0f || fminf(fminf(zf0, zf1), zf2) < 0.0f ||
-                fminf(fminf(c0.x + g0, c1.x + g1), c2.x + g2) < 0.0f || fminf(fminf(g0 - c0.x, g1 - c1.x), g2 - c2.x) < 0.0f ||
-                fminf(fminf(c0.y + g0, c1.y + g1), c2.y + g2) < 0.0f || fminf(fminf(g0 - c0.y, g1 - c1.y), g2 - c2.y) < 0.0f;
-    if (need_clip) return;
-    Snapped s0, s1, s2;
-    bool ok0 = snap_vertex(c0.x, c0.y, c0.z, c0.w, half_w, half_h, s0, fc.sub_dx, fc.sub_dy);
-    bool ok1 = snap_vertex(c1.x, c1.y, c1.z, c1.w, half_w, half_h, s1, fc.sub_dx, fc.sub_dy);
-    bool ok2 = snap_vertex(c2.x, c2.y, c2.z, c2.w, half_w, half_h, s2, fc.sub_dx, fc.sub_dy);
-    if (ok0 && ok1 && ok2) emit = make_record(s0, s1, s2, gid, fc, rec, tr) && any_owned(tr, fc);
+    const float clip_m = fminf(fminf(fminf(fminf(fminf(c0.z, c1.z), c2.z), fminf(fminf(zf0, zf1), zf2)),
+                                     fminf(fminf(fminf(c0.x + g0, c1.x + g1), c2.x + g2), fminf(fminf(g0 - c0.x, g1 - c1.x), g2 - c2.x))),
+                               fminf(fminf(fminf(c0.y + g0, c1.y + g1), c2.y + g2), fminf(fminf(g0 - c0.y, g1 - c1.y), g2 - c2.y)));
+    const bool go = finite && !(out_m < 0.0f);
+    need_clip = go && clip_m < 0.0f;
+    if (go && !need_clip) {
+        Snapped s0, s1, s2;
+        const bool ok0 = snap_vertex(c0.x, c0.y, c0.z, c0.w, half_w, half_h, s0, fc.sub_dx, fc.sub_dy);
+        const bool ok1 = snap_vertex(c1.x, c1.y, c1.z, c1.w, half_w, half_h, s1, fc.sub_dx, fc.sub_dy);
+        const bool ok2 = snap_vertex(c2.x, c2.y, c2.z, c2.w, half_w, half_h, s2, fc.sub_dx, fc.sub_dy);
+        const bool rec_ok = make_record(s0, s1, s2, gid, fc, rec, tr);
+        emit = ok0 && ok1 && ok2 && rec_ok && any_owned(tr, fc);
+    }
 }
 
 // Direct raster, wave-cooperative.  Per wave only a quarter of the triangles survive culling, and a
