@@ -1398,10 +1398,10 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(
         covered[k] = i < fc.width && j < fc.height && id != RND_NONE;
         if constexpr (kSamples > 1) covered[k] = covered[k] && !reuse;
         if (covered[k] && !guard(id < fc.n_tris, fb.counters, kGuardShade)) covered[k] = false;
-        if (kSamples == 1 || !reuse) {
-            px[k] = PixelInputs{};
-            px[k].cr = fc.clear_hdr[0]; px[k].cg = fc.clear_hdr[1]; px[k].cb = fc.clear_hdr[2];
-        }
+        // the fragment's inputs go to `fresh`, left unset on lanes without a fragment; the defaults are
+        // selected once, after the item paths have merged (initializing up front made every merge point
+        // of the branches below re-materialize them)
+        PixelInputs fresh;
         uint32_t it = 0;
         if (covered[k]) it = bases_in_lds ? find_item(s_bases, fc.n_items, id) : find_item(fb.tri_bases, fc.n_items, id);
         const unsigned long long cov = __ballot(covered[k]);
@@ -1411,7 +1411,7 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(
             if (__ballot(covered[k] && it != lead) == 0ull) {
                 // the usual case: every covered pixel of the wave belongs to one draw item
                 const DrawItem d = load_item_uniform(fb.items, lead_s);
-                if (covered[k]) prepare_pixel<kShadows>(d, fc, fb.clip, fb.textures, id, i, j, px[k], fb.counters);
+                if (covered[k]) prepare_pixel<kShadows>(d, fc, fb.clip, fb.textures, id, i, j, fresh, fb.counters);
             } else if (covered[k]) {
                 // waterfall: one pass per distinct draw item among the wave's pixels
                 for (unsigned long long pending = __ballot(true); pending;) {
@@ -1420,9 +1420,16 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(
                     pending &= ~__ballot(mine);
                     if (mine) {
                         const DrawItem d = load_item_uniform(fb.items, cur_s);
-                        prepare_pixel<kShadows>(d, fc, fb.clip, fb.textures, id, i, j, px[k], fb.counters);
+                        prepare_pixel<kShadows>(d, fc, fb.clip, fb.textures, id, i, j, fresh, fb.counters);
                     }
                 }
+            }
+        }
+        if (kSamples == 1 || !reuse) {
+            if (covered[k]) px[k] = fresh;
+            else {
+                px[k] = PixelInputs{};
+                px[k].cr = fc.clear_hdr[0]; px[k].cg = fc.clear_hdr[1]; px[k].cb = fc.clear_hdr[2];
             }
         }
         if (covered[k]) {
