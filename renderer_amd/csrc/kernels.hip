@@ -1477,7 +1477,14 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(
                 }
             }
             for (unsigned long long km = __ballot(keep); km; km &= km - 1ull) {
-                const GpuLight& L = s_lights[group + (uint32_t)(__ffsll((long long)km) - 1)];
+                // the whole light at once (16 B LDS reads, one wait) rather than field by field as the
+                // branches below get to them
+                GpuLight L;
+                {
+                    const uint4* src = reinterpret_cast<const uint4*>(&s_lights[group + (uint32_t)(__ffsll((long long)km) - 1)]);
+                    uint4* dst = reinterpret_cast<uint4*>(&L);
+                    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+                }
 #if RND_FAST_SHADE
                 if constexpr (PPT == 2) { add_light_pair<kShadows>(L, pp, fb.shadow_sets, fc); continue; }
 #endif
