@@ -190,8 +190,10 @@ def main():
             b, gathered = pending.pop(0)
             with torch.cuda.stream(stream):
                 stream.wait_event(collected[b])
-                for r in range(world):
-                    vs.api.detile(vs._ctx, r, world, C.c_void_p(gathered[r].data_ptr()))
+                ga = gathers[b].gathered_all
+                rc = vs.api.detile_gathered(vs._ctx, world, C.c_void_p(ga.data_ptr()), ga.stride(0))
+                if rc:
+                    raise RuntimeError("detile failed: " + (vs.api.last_error(vs._ctx) or b"").decode())
                 detiled[b].record(stream)
 
     def fence():

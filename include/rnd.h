@@ -209,6 +209,10 @@ int rnd_set_tiles_output(rnd_ctx* ctx, void* dev_ptr, uint64_t n_bytes);
 /* On the gathering rank: scatter `src_rank`'s tile-major buffer (device pointer on this
  * context's device) into this context's row-major RGBA8 frame. */
 int rnd_detile(rnd_ctx* ctx, uint32_t src_rank, uint32_t world, const void* dev_tiles);
+/* The same for all ranks at once: rank r's buffer starts at dev_gathered + r * stride_bytes (the
+ * layout of a gather into one [world, stride] tensor); stride_bytes a multiple of 4 and at least
+ * the largest rank's n_owned_tiles * tile_px*tile_px*4.  One launch instead of `world`. */
+int rnd_detile_gathered(rnd_ctx* ctx, uint32_t world, const void* dev_gathered, uint64_t stride_bytes);
 /* Sort-last: device pointer of the packed (depth bits << 32 | rgba8) u64 frame, width*height
  * entries, row-major; min-reducing these across ranks is the depth composite. */
 int rnd_packed_device_ptr(rnd_ctx* ctx, void** dev_ptr, uint64_t* n_bytes);

@@ -106,6 +106,7 @@ extern "C" {
     pub fn rnd_tile_info(ctx: *const rnd_ctx, tile_px: *mut u32, n_owned_tiles: *mut u32, n_tiles_total: *mut u32) -> c_int;
     pub fn rnd_tiles_device_ptr(ctx: *mut rnd_ctx, dev_ptr: *mut *mut c_void, n_bytes: *mut u64) -> c_int;
     pub fn rnd_set_tiles_output(ctx: *mut rnd_ctx, dev_ptr: *mut c_void, n_bytes: u64) -> c_int;
+    pub fn rnd_detile_gathered(ctx: *mut rnd_ctx, world: u32, dev_gathered: *const c_void, stride_bytes: u64) -> c_int;
     pub fn rnd_detile(ctx: *mut rnd_ctx, src_rank: u32, world: u32, dev_tiles: *const c_void) -> c_int;
     pub fn rnd_packed_device_ptr(ctx: *mut rnd_ctx, dev_ptr: *mut *mut c_void, n_bytes: *mut u64) -> c_int;
     pub fn rnd_unpack(ctx: *mut rnd_ctx, dev_packed: *const c_void) -> c_int;

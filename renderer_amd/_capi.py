@@ -103,6 +103,7 @@ SIGNATURES = {
     "tiles_device_ptr": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     "set_tiles_output": (C.c_int, [_P, _P, C.c_uint64]),
     "detile": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P]),
+    "detile_gathered": (C.c_int, [_P, C.c_uint32, _P, C.c_uint64]),
     "packed_device_ptr": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     "unpack": (C.c_int, [_P, _P]),
     "set_stream": (C.c_int, [_P, _P]),
@@ -110,7 +111,7 @@ SIGNATURES = {
 }
 
 # entry points that only make sense with device memory; a host-only library may omit them
-DEVICE_ONLY = {"mean_timings", "set_tiles_output", "tiles_device_ptr", "detile", "packed_device_ptr", "unpack", "set_stream",
+DEVICE_ONLY = {"mean_timings", "set_tiles_output", "tiles_device_ptr", "detile", "detile_gathered", "packed_device_ptr", "unpack", "set_stream",
                "color_device_ptr"}
 
 

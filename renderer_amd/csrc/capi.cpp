@@ -188,6 +188,9 @@ int rnd_set_tiles_output(rnd_ctx* ctx, void* p, uint64_t n) { return guard(ctx, 
 int rnd_detile(rnd_ctx* ctx, uint32_t src_rank, uint32_t world, const void* dev_tiles) {
     return guard(ctx, [&](rnd::VisualServer& v) { v.detile(src_rank, world, dev_tiles); });
 }
+int rnd_detile_gathered(rnd_ctx* ctx, uint32_t world, const void* dev_gathered, uint64_t stride_bytes) {
+    return guard(ctx, [&](rnd::VisualServer& v) { v.detile_gathered(world, dev_gathered, stride_bytes); });
+}
 int rnd_packed_device_ptr(rnd_ctx* ctx, void** p, uint64_t* n) {
     REQUIRE(ctx, p && n, "null output");
     return guard(ctx, [&](rnd::VisualServer& v) { v.packed_device_ptr(p, n); });

@@ -66,6 +66,9 @@ void launch_split_positions(const rnd_vertex* verts, uint32_t n, float* px, floa
 // tile-major RGBA8 of `n` tiles (list `tiles`) -> row-major frame
 void launch_detile(const uint8_t* tiles_rgba8, const uint32_t* tiles, uint32_t n, const FrameConst& fc,
                    uint8_t* frame_rgba8, hipStream_t stream);
+// every rank's gathered tile-major buffer -> row-major frame, one launch
+void launch_detile_gathered(const uint8_t* gathered, uint64_t stride_bytes, uint32_t world, const FrameConst& fc,
+                            uint8_t* frame_rgba8, hipStream_t stream);
 // show_texture.wgsl for a 3D target whose size differs from the surface (render_size_factor != 1):
 // hdr (w x h, rgb f32 holding f16 values) sampled at the surface's pixel centres, nearest or
 // linear, then tone map + sRGB into the sw x sh RGBA8 frame

@@ -1574,6 +1574,23 @@ __global__ void k_detile(const uint32_t* __restrict__ tiles_rgba8, const uint32_
     }
 }
 
+// All ranks' tile-major buffers (rank r at gathered + r * stride_words) into the row-major frame in one
+// launch, one workgroup per tile of the frame.  With full-width stripes of kOwnerGroup tile rows dealt
+// round-robin, tile (tx, ty) belongs to rank (ty / kOwnerGroup) % world and is number
+// ((ty / kOwnerGroup / world) * kOwnerGroup + ty % kOwnerGroup) * tiles_x + tx of that rank's ascending list.
+__global__ void k_detile_gathered(const uint32_t* __restrict__ gathered, uint64_t stride_words, uint32_t world,
+                                  FrameConst fc, uint32_t* frame) {
+    const uint32_t tile = blockIdx.x, tx = tile % fc.tiles_x, ty = tile / fc.tiles_x;
+    const uint32_t group = ty / kOwnerGroup, owner = group % world;
+    const uint32_t compact = ((group / world) * kOwnerGroup + ty % kOwnerGroup) * fc.tiles_x + tx;
+    const uint32_t* src = gathered + (size_t)owner * stride_words + (size_t)compact * kTilePixels;
+    const uint32_t tile_x0 = tx * kTile, tile_y0 = ty * kTile;
+    for (uint32_t local = threadIdx.x; local < kTilePixels; local += blockDim.x) {
+        uint32_t i = tile_x0 + (local & (kTile - 1)), j = tile_y0 + local / kTile;
+        if (i < fc.width && j < fc.height) frame[(size_t)j * fc.width + i] = src[local];
+    }
+}
+
 __global__ void k_present(const float* __restrict__ hdr, uint32_t w, uint32_t h, uint32_t* __restrict__ frame,
                           uint32_t sw, uint32_t sh, uint32_t linear, uint32_t tone) {
     const uint32_t i = blockIdx.x * 64u + (threadIdx.x & 63u), j = blockIdx.y * 4u + (threadIdx.x >> 6);
@@ -1687,6 +1704,11 @@ void launch_detile(const uint8_t* tiles_rgba8, const uint32_t* tiles, uint32_t n
     if (!n) return;
     hipLaunchKernelGGL(k_detile, dim3(n), dim3(256), 0, stream, reinterpret_cast<const uint32_t*>(tiles_rgba8), tiles,
                        fc, reinterpret_cast<uint32_t*>(frame_rgba8));
+}
+void launch_detile_gathered(const uint8_t* gathered, uint64_t stride_bytes, uint32_t world, const FrameConst& fc,
+                            uint8_t* frame_rgba8, hipStream_t stream) {
+    hipLaunchKernelGGL(k_detile_gathered, dim3(fc.tiles_x * fc.tiles_y), dim3(256), 0, stream,
+                       reinterpret_cast<const uint32_t*>(gathered), stride_bytes / 4, world, fc, reinterpret_cast<uint32_t*>(frame_rgba8));
 }
 void launch_present(const float* hdr, uint32_t w, uint32_t h, uint8_t* frame_rgba8, uint32_t sw, uint32_t sh,
                     bool linear, uint32_t tone, hipStream_t stream) {

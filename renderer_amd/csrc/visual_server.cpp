@@ -815,6 +815,19 @@ void VisualServer::detile(uint32_t src_rank, uint32_t world, const void* dev_til
     HIP_CHECK(hipGetLastError());
 }
 
+void VisualServer::detile_gathered(uint32_t world, const void* dev_gathered, uint64_t stride_bytes) {
+    if (!dev_gathered || world == 0 || stride_bytes % 4) throw Error(RND_ERR_INVALID, "bad detile arguments");
+    // the largest share is rank 0's (stripes are dealt from rank 0)
+    uint64_t rows0 = 0;
+    for (uint32_t first = 0; first < tiles_y_; first += kOwnerGroup * world) rows0 += std::min(kOwnerGroup, tiles_y_ - first);
+    if (stride_bytes < rows0 * tiles_x_ * kTilePixels * 4) throw Error(RND_ERR_INVALID, "gathered stride smaller than the largest rank's tiles");
+    use_device();
+    FrameConst fc = fc_;
+    fc.width = width_; fc.height = height_; fc.tiles_x = tiles_x_; fc.tiles_y = tiles_y_;
+    launch_detile_gathered(static_cast<const uint8_t*>(dev_gathered), stride_bytes, world, fc, d_frame_.ptr, stream_);
+    HIP_CHECK(hipGetLastError());
+}
+
 void VisualServer::packed_device_ptr(void** p, uint64_t* bytes) {
     use_device();
     if (scaled()) throw Error(RND_ERR_UNSUPPORTED, "the packed (sort-last) frame is not built for render_size_factor != 1");

@@ -125,6 +125,7 @@ public:
     void tiles_device_ptr(void** p, uint64_t* bytes);
     void set_tiles_output(void* dev_ptr, uint64_t bytes);
     void detile(uint32_t src_rank, uint32_t world, const void* dev_tiles);
+    void detile_gathered(uint32_t world, const void* dev_gathered, uint64_t stride_bytes);
     void packed_device_ptr(void** p, uint64_t* bytes);
     void unpack(const void* dev_packed);
     void set_stream(hipStream_t s);

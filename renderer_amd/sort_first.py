@@ -45,7 +45,10 @@ class TileGather:
         dist.all_gather(counts, t)
         self.counts = [int(c.item()) for c in counts]
         self.tiles = torch.zeros(max(max(self.counts), 1) * self.tile_bytes, dtype=torch.uint8, device=device)
-        self.gathered = [torch.empty_like(self.tiles) for _ in range(world)] if rank == 0 else None
+        # rank 0: one contiguous [world, stride] tensor, so one kernel can scatter all ranks' tiles
+        # (rnd_detile_gathered); the gather list is its rows
+        self.gathered_all = torch.empty((world, self.tiles.numel()), dtype=torch.uint8, device=device) if rank == 0 else None
+        self.gathered = [self.gathered_all[r] for r in range(world)] if rank == 0 else None
 
     def gather(self):
         """Collect every rank's `tiles` buffer on rank 0 (a send/recv group, no ring)."""

@@ -267,6 +267,9 @@ class VisualServer:
     def detile(self, src_rank, world, dev_ptr):
         self._check(self.api.detile(self._ctx, int(src_rank), int(world), C.c_void_p(dev_ptr)))
 
+    def detile_gathered(self, world, dev_ptr, stride_bytes):
+        self._check(self.api.detile_gathered(self._ctx, int(world), C.c_void_p(dev_ptr), int(stride_bytes)))
+
     def unpack(self, dev_ptr):
         self._check(self.api.unpack(self._ctx, C.c_void_p(dev_ptr)))
 

@@ -47,6 +47,30 @@ def test_sort_first_tiles_into_external_buffers_and_detile():
     diff = np.abs(frame.astype(int) - cpu.read_color_rgba8().astype(int))
     assert diff.max() <= 1
     assert frame[..., 3].min() == 255          # every pixel was written by exactly the owning rank
+    # the same from one [world, stride] tensor in one launch (rnd_detile_gathered), for several world sizes
+    for world2 in (2, 3, 5, 8):
+        stride = 0
+        parts = []
+        for r in range(world2):
+            vs = VisualServer(s.width, s.height, device=0)
+            vs.set_tile_partition(r, world2)
+            s.populate(vs)
+            vs.render()
+            vs.finish()
+            ptr, nbytes = vs.tiles_device_ptr()
+            parts.append((vs, ptr, nbytes))
+            stride = max(stride, nbytes)
+        allbuf = torch.zeros((world2, stride), dtype=torch.uint8, device="cuda")
+        for r, (vs, ptr, nbytes) in enumerate(parts):
+            assert hip.hipMemcpy(ctypes.c_void_p(allbuf[r].data_ptr()), ctypes.c_void_p(ptr), ctypes.c_size_t(nbytes), 3) == 0
+        root2 = parts[0][0]
+        root2.detile_gathered(world2, allbuf.data_ptr(), allbuf.stride(0))
+        root2.finish()
+        ptr, nbytes = root2.color_device_ptr()
+        frame2 = np.empty((s.height, s.width, 4), np.uint8)
+        assert hip.hipDeviceSynchronize() == 0
+        assert hip.hipMemcpy(ctypes.c_void_p(frame2.ctypes.data), ctypes.c_void_p(ptr), ctypes.c_size_t(nbytes), 2) == 0
+        assert (frame2 == frame).all(), world2
 
 
 def test_sort_last_packed_min_composite():
