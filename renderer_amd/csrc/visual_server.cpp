@@ -72,12 +72,12 @@ VisualServer::~VisualServer() {
     if (stream_) (void)hipStreamSynchronize(stream_);
     for (auto& kv : meshes_)
         for (auto& s : kv.second.submeshes) { s.vertex_buffer.release(); s.positions.release(); s.index_buffer.release(); s.chunks.release(); }
-    d_items_.release(); d_vert_bases_.release(); d_tri_bases_.release(); d_lights_.release(); d_clip_.release();
-    d_records_.release(); d_tilewords_.release(); d_clip_queue_.release(); d_chunk_count_.release(); d_unit_bases_.release(); d_vblock_needed_.release(); d_active_units_.release(); d_tile_count_.release();
+    d_tables_.release(); d_clip_.release();
+    d_records_.release(); d_tilewords_.release(); d_clip_queue_.release(); d_chunk_count_.release(); d_vblock_needed_.release(); d_active_units_.release(); d_tile_count_.release();
     d_tile_offset_.release(); d_tile_cursor_.release(); d_entries_.release(); d_counters_.release();
     for (auto& kv : textures_) kv.second.texels.release();
     d_textures_.release();
-    d_shadow_items_.release(); d_shadow_sets_.release(); d_shadow_order_.release();
+    d_shadow_order_.release();
     for (auto& b : shadow_layers_) b.release();
     d_launch_order_.release(); d_vis_.release(); d_frame_.release(); d_tiles_.release(); d_packed_.release();
     d_hdr_.release();
@@ -471,8 +471,6 @@ void VisualServer::enqueue_frame(bool want_hdr) {
             for (int c = 0; c < 3; ++c) rl.cascades[c].to_cols_array(sets[k].world_to_light[c]);
             for (uint32_t c = 0; c < kShadowCascades; ++c) sets[k].layers[c] = shadow_layers_[k].ptr + (size_t)c * kShadowTiles * kTilePixels;
         }
-        d_shadow_items_.ensure(std::max<size_t>(shadow_items.size(), 1));
-        d_shadow_sets_.ensure(n_sets);
         if (!d_shadow_order_.ptr) {
             std::vector<TileRef> order(kShadowTiles);
             for (uint32_t t = 0; t < kShadowTiles; ++t) order[t] = TileRef{t, t};
@@ -501,15 +499,11 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     if (cap_.clip_queue < std::max<uint32_t>(fc.n_tris / 8, 65536)) cap_.clip_queue = std::max<uint32_t>(fc.n_tris / 8, 65536);
     const uint64_t want_entries = std::max<uint64_t>(4ull * cap_.records + 16ull * n_tiles, 1u << 20);
     if (cap_.entries < want_entries) cap_.entries = (uint32_t)std::min<uint64_t>(want_entries, 0xFFFFFFF0ull);
-    d_items_.ensure(std::max<size_t>(items.size(), 1));
-    d_vert_bases_.ensure(vert_bases.size()); d_tri_bases_.ensure(tri_bases.size());
-    d_lights_.ensure(std::max<size_t>(lights.size(), 1));
     d_clip_.ensure(std::max<size_t>(fc.n_verts, 1));
     d_records_.ensure(cap_.records); d_tilewords_.ensure(2 * (size_t)cap_.records);
     d_clip_queue_.ensure(cap_.clip_queue);
     d_chunk_count_.ensure(std::max<size_t>(2 * (size_t)fc.n_units, 2));
     d_active_units_.ensure(std::max<size_t>(2 * (size_t)fc.n_units, 2));
-    d_unit_bases_.ensure(unit_bases.size());
     d_vblock_needed_.ensure((size_t)fc.n_verts / kVertexBlock + 2);
     d_entries_.ensure(cap_.entries);
     if (world_ > 1) d_tiles_.ensure(std::max<size_t>((size_t)n_owned_ * kTilePixels * 4, 4));
@@ -540,29 +534,28 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     std::memcpy(h + off_tb, tri_bases.data(), tri_bases.size() * 4);
     std::memcpy(h + off_ub, unit_bases.data(), unit_bases.size() * 4);
     if (!lights.empty()) std::memcpy(h + off_li, lights.data(), lights.size() * sizeof(GpuLight));
-    if (!items.empty()) HIP_CHECK(hipMemcpyAsync(d_items_.ptr, h + off_items, items.size() * sizeof(DrawItem), hipMemcpyHostToDevice, stream_));
-    HIP_CHECK(hipMemcpyAsync(d_vert_bases_.ptr, h + off_vb, vert_bases.size() * 4, hipMemcpyHostToDevice, stream_));
-    HIP_CHECK(hipMemcpyAsync(d_tri_bases_.ptr, h + off_tb, tri_bases.size() * 4, hipMemcpyHostToDevice, stream_));
-    HIP_CHECK(hipMemcpyAsync(d_unit_bases_.ptr, h + off_ub, unit_bases.size() * 4, hipMemcpyHostToDevice, stream_));
-    if (!lights.empty()) HIP_CHECK(hipMemcpyAsync(d_lights_.ptr, h + off_li, lights.size() * sizeof(GpuLight), hipMemcpyHostToDevice, stream_));
     if (n_sets) {
         std::memcpy(h + off_si, shadow_items.data(), shadow_items.size() * sizeof(DrawItem));
         std::memcpy(h + off_ss, sets.data(), n_sets * sizeof(ShadowSet));
-        if (!shadow_items.empty()) HIP_CHECK(hipMemcpyAsync(d_shadow_items_.ptr, h + off_si, shadow_items.size() * sizeof(DrawItem), hipMemcpyHostToDevice, stream_));
-        HIP_CHECK(hipMemcpyAsync(d_shadow_sets_.ptr, h + off_ss, n_sets * sizeof(ShadowSet), hipMemcpyHostToDevice, stream_));
     }
+    // one device block with the same layout, one copy (each hipMemcpyAsync costs the host ~8 us: with
+    // a rank's share of a partitioned frame at ~0.13 ms of GPU time, the enqueue was the longer side)
+    d_tables_.ensure(total + total / 2);
+    HIP_CHECK(hipMemcpyAsync(d_tables_.ptr, h, total, hipMemcpyHostToDevice, stream_));
+    uint8_t* const tb = d_tables_.ptr;
     HIP_CHECK(hipEventRecord(st.done, stream_));
     st.in_flight = true;
 
     FrameBuffers fb{};
-    fb.items = d_items_.ptr; fb.vert_bases = d_vert_bases_.ptr; fb.tri_bases = d_tri_bases_.ptr; fb.lights = d_lights_.ptr;
+    fb.items = reinterpret_cast<const DrawItem*>(tb + off_items); fb.vert_bases = reinterpret_cast<const uint32_t*>(tb + off_vb);
+    fb.tri_bases = reinterpret_cast<const uint32_t*>(tb + off_tb); fb.lights = reinterpret_cast<const GpuLight*>(tb + off_li);
     fb.textures = d_textures_.ptr;
     fb.alpha_test = frame_alpha_test_ ? 1u : 0u;
     fb.has_textures = frame_textured_ ? 1u : 0u;
-    fb.shadow_sets = n_sets ? d_shadow_sets_.ptr : nullptr;      // null selects the shading kernel without the lookup
+    fb.shadow_sets = n_sets ? reinterpret_cast<const ShadowSet*>(tb + off_ss) : nullptr;      // null selects the shading kernel without the lookup
     fb.clip = d_clip_.ptr; fb.records = d_records_.ptr; fb.tilewords = reinterpret_cast<uint2*>(d_tilewords_.ptr); fb.clip_queue = d_clip_queue_.ptr;
     fb.chunk_count = d_chunk_count_.ptr;
-    fb.unit_bases = d_unit_bases_.ptr; fb.active_units = reinterpret_cast<uint2*>(d_active_units_.ptr); fb.vblock_needed = d_vblock_needed_.ptr;
+    fb.unit_bases = reinterpret_cast<const uint32_t*>(tb + off_ub); fb.active_units = reinterpret_cast<uint2*>(d_active_units_.ptr); fb.vblock_needed = d_vblock_needed_.ptr;
     fb.tile_count = d_tile_count_.ptr; fb.tile_offset = d_tile_offset_.ptr; fb.tile_cursor = d_tile_cursor_.ptr;
     fb.entries = d_entries_.ptr; fb.counters = d_counters_.ptr;
     fb.launch_order = d_launch_order_.ptr; fb.n_owned = n_owned_;
@@ -573,18 +566,28 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     fb.packed = want_packed_ ? d_packed_.ptr : nullptr;
     fb.hdr = want_hdr ? d_hdr_.ptr : nullptr;
 
-    EventSet& es = event_sets_[event_next_];
-    if (es.pending) harvest(es);
-    last_set_ = (int)event_next_;
-    event_next_ = (event_next_ + 1) % kEventSets;
-    hipEvent_t* ev_ = es.ev;
+    // per-kernel timing events on a sample of the frames (every kTimingStride-th, and the first few):
+    // eight event records per frame are a noticeable share of the host's enqueue time
+    const bool timed = frame_counter_ < 4 || frame_counter_ % kTimingStride == 0;
+    ++frame_counter_;
+    hipEvent_t* ev_ = nullptr;
+    EventSet* timed_set = nullptr;
+    if (timed) {
+        EventSet& es = event_sets_[event_next_];
+        if (es.pending) harvest(es);
+        last_set_ = (int)event_next_;
+        event_next_ = (event_next_ + 1) % kEventSets;
+        ev_ = es.ev;
+        timed_set = &es;
+    }
+    auto mark = [&](int k) { if (ev_) HIP_CHECK(hipEventRecord(ev_[k], stream_)); };
     // shadow cascades: depth-only passes of the same pipeline (cull, transform, setup, bins, raster)
     // into kShadowSize^2 visibility buffers, one per (directional light, cascade)
-    HIP_CHECK(hipEventRecord(ev_[7], stream_));
+    mark(7);
     for (uint32_t k = 0; k < n_sets; ++k)
         for (uint32_t c = 0; c < kShadowCascades; ++c) {
             FrameBuffers sfb = fb;
-            sfb.items = d_shadow_items_.ptr; sfb.lights = nullptr; sfb.shadow_sets = nullptr; sfb.alpha_test = 0;
+            sfb.items = reinterpret_cast<const DrawItem*>(tb + off_si); sfb.lights = nullptr; sfb.shadow_sets = nullptr; sfb.alpha_test = 0;
             sfb.counters = d_counters_.ptr + 1 + k * kShadowCascades + c;
             sfb.launch_order = d_shadow_order_.ptr; sfb.n_owned = kShadowTiles;
             sfb.vis = shadow_layers_[k].ptr + (size_t)c * kShadowTiles * kTilePixels;
@@ -603,18 +606,18 @@ void VisualServer::enqueue_frame(bool want_hdr) {
             launch_bin(sfb, sfc, cap_, stream_);
             launch_raster(sfb, sfc, cap_, stream_);
         }
-    HIP_CHECK(hipEventRecord(ev_[0], stream_));
+    mark(0);
     launch_clear(fb, fc, stream_);      // visibility words, tile counts, vertex-block flags, frame counters
     launch_cull(fb, fc, stream_);       // work units that can reach the view volume and this context's stripes
     launch_transform(fb, fc, stream_);
-    HIP_CHECK(hipEventRecord(ev_[1], stream_));
+    mark(1);
     launch_setup(fb, fc, cap_, stream_);
     launch_clip(fb, fc, cap_, stream_);
-    HIP_CHECK(hipEventRecord(ev_[2], stream_));
+    mark(2);
     launch_scan(fb, fc, cap_, stream_);
-    HIP_CHECK(hipEventRecord(ev_[3], stream_));
+    mark(3);
     launch_bin(fb, fc, cap_, stream_);
-    HIP_CHECK(hipEventRecord(ev_[4], stream_));
+    mark(4);
     launch_raster(fb, fc, cap_, stream_);
     // MSAA: the other samples' visibility planes, one more geometry pass each with the snapped
     // vertices moved so that the sample sits on the pixel centre (clip positions are shared)
@@ -632,12 +635,12 @@ void VisualServer::enqueue_frame(bool want_hdr) {
         launch_bin(mfb, mfc, cap_, stream_);
         launch_raster(mfb, mfc, cap_, stream_);
     }
-    HIP_CHECK(hipEventRecord(ev_[5], stream_));
+    mark(5);
     launch_shade(fb, fc, stream_);
     if (scaled())   // show_texture.wgsl over the surface (visual_server.rs:629-633: filtered sampler above factor 1)
         launch_present(d_hdr_.ptr, width_, height_, d_present_.ptr, surface_w_, surface_h_, render_size_factor_ > 1.0f, tone_mapping_, stream_);
-    HIP_CHECK(hipEventRecord(ev_[6], stream_));
-    es.pending = true;
+    mark(6);
+    if (timed_set) timed_set->pending = true;
     HIP_CHECK(hipMemcpyAsync(h_counters_, d_counters_.ptr, n_counter_sets_ * sizeof(FrameCounters), hipMemcpyDeviceToHost, stream_));
     HIP_CHECK(hipGetLastError());
     frame_pending_ = true;

@@ -169,6 +169,8 @@ private:
     };
     EventSet event_sets_[kEventSets];
     uint32_t event_next_ = 0;
+    static constexpr uint64_t kTimingStride = 4;
+    uint64_t frame_counter_ = 0;
     int last_set_ = -1;
     double timing_sum_[8] = {};
     uint32_t timing_frames_ = 0;
@@ -193,17 +195,13 @@ private:
     float ambient_light_[4] = {0.3f, 0.5f, 0.9f, 0.04f};
 
     // device state
-    DeviceBuffer<DrawItem> d_items_;
-    DeviceBuffer<uint32_t> d_vert_bases_, d_tri_bases_;
-    DeviceBuffer<GpuLight> d_lights_;
+    DeviceBuffer<uint8_t> d_tables_;                // per-frame tables (items, bases, lights, shadow items and sets), one upload
     DeviceBuffer<float4> d_clip_;
     DeviceBuffer<SetupRecord> d_records_;
-    DeviceBuffer<uint32_t> d_tilewords_, d_clip_queue_, d_chunk_count_, d_unit_bases_, d_vblock_needed_, d_active_units_, d_tile_count_, d_tile_offset_, d_tile_cursor_, d_entries_;
+    DeviceBuffer<uint32_t> d_tilewords_, d_clip_queue_, d_chunk_count_, d_vblock_needed_, d_active_units_, d_tile_count_, d_tile_offset_, d_tile_cursor_, d_entries_;
     DeviceBuffer<FrameCounters> d_counters_;        // [0] main pass, then one per shadow pass
     uint32_t n_counter_sets_ = 1, h_counter_sets_ = 0;
     // shadow cascades of the directional lights
-    DeviceBuffer<DrawItem> d_shadow_items_;
-    DeviceBuffer<ShadowSet> d_shadow_sets_;
     DeviceBuffer<TileRef> d_shadow_order_;
     std::vector<DeviceBuffer<uint64_t>> shadow_layers_;   // per shadowed light: kShadowCascades visibility buffers
     DeviceBuffer<TileRef> d_launch_order_;
