@@ -12,6 +12,7 @@ struct TileRef {
 };
 
 struct FrameBuffers {
+    const FrameConst* frame_const;  // this pass's constants, in the per-frame table block
     // per-frame scene tables
     const DrawItem* items;
     const uint32_t* vert_bases;     // n_items + 1

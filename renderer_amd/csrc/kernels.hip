@@ -42,6 +42,17 @@ __device__ __forceinline__ bool guard(bool ok, FrameCounters* counters, uint32_t
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
+// The frame's constants live in device memory (uploaded with the per-frame tables), not in the kernel
+// arguments: the arguments of a frame's kernels then only change when buffers or the scene's shape
+// do, so the launch sequence can be replayed as a HIP graph.  They are read through the constant
+// address space — scalar loads the compiler may repeat or re-order like kernel arguments — field by
+// field where used (copying the struct up front kept all 70 dwords live: SGPR spills into VGPR lanes).
+typedef const __attribute__((address_space(4))) FrameConst& FrameConstRef;
+typedef const __attribute__((address_space(4))) float* cptr_f32;
+__device__ __forceinline__ FrameConstRef frame_const_ref(const FrameConst* p) {
+    return *(const __attribute__((address_space(4))) FrameConst*)p;
+}
+
 // largest k in [0, n) with bases[k] <= id (bases[0] == 0, ascending)
 __device__ __forceinline__ uint32_t find_item(const uint32_t* __restrict__ bases, uint32_t n, uint32_t id) {
     uint32_t lo = 0, hi = n;
@@ -103,7 +114,7 @@ __device__ __forceinline__ DrawItem load_item_uniform(const DrawItem* items, uin
 
 // vs_main's clip position (render_mesh.wgsl:42-82).  K1 stores it; the shading kernel re-derives
 // it from the object-space position it gathers anyway: same inputs, same operations, same bits.
-__device__ __forceinline__ float4 clip_position(const DrawItem& d, const FrameConst& fc, float x, float y, float z) {
+__device__ __forceinline__ float4 clip_position(const DrawItem& d, FrameConstRef fc, float x, float y, float z) {
     float4 c;
     if ((d.flags & kItemBillboardMask) == RND_BILLBOARD_FIXED_SIZE) {
         c = make_float4(d.fixed_clip[0] + x * 0.4f, d.fixed_clip[1] + y * 0.4f, d.fixed_clip[2], d.fixed_clip[3]);
@@ -113,7 +124,7 @@ __device__ __forceinline__ float4 clip_position(const DrawItem& d, const FrameCo
         float wy = ((m[1] * x + m[5] * y) + m[9] * z) + m[13];
         float wz = ((m[2] * x + m[6] * y) + m[10] * z) + m[14];
         float ww = ((m[3] * x + m[7] * y) + m[11] * z) + m[15];
-        const float* p = fc.pv;
+        cptr_f32 p = fc.pv;
         c.x = ((p[0] * wx + p[4] * wy) + p[8] * wz) + p[12] * ww;
         c.y = ((p[1] * wx + p[5] * wy) + p[9] * wz) + p[13] * ww;
         c.z = ((p[2] * wx + p[6] * wy) + p[10] * wz) + p[14] * ww;
@@ -130,7 +141,8 @@ __device__ __forceinline__ float4 clip_position(const DrawItem& d, const FrameCo
 // ------------------------------------------------------------------------------------------
 // Frame clear: visibility words of the owned tiles to (depth 1.0, no triangle), tile counts and
 // frame counters to zero.  One workgroup per owned tile.
-__global__ __launch_bounds__(256) void k_clear(FrameBuffers fb, FrameConst fc) {
+__global__ __launch_bounds__(256) void k_clear(FrameBuffers fb) {
+    FrameConstRef fc = frame_const_ref(fb.frame_const);
     if (blockIdx.x < fb.n_owned) {
         const uint32_t tile = fb.launch_order[blockIdx.x].tile;
         typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
@@ -151,7 +163,8 @@ __global__ __launch_bounds__(256) void k_clear(FrameBuffers fb, FrameConst fc) {
 // results), or, on a sort-first partition, when the rows the box can cover (padded by two pixels)
 // hold no tile this context owns.  Survivors are appended to active_units and flag the vertex
 // blocks they read.
-__global__ __launch_bounds__(256) void k_cull(FrameBuffers fb, FrameConst fc) {
+__global__ __launch_bounds__(256) void k_cull(FrameBuffers fb) {
+    FrameConstRef fc = frame_const_ref(fb.frame_const);
     const uint32_t u = blockIdx.x * 256u + threadIdx.x;
     const uint32_t lane = lane_id();
     bool active = false;
@@ -216,9 +229,10 @@ __global__ __launch_bounds__(256) void k_cull(FrameBuffers fb, FrameConst fc) {
 }
 
 __global__ __launch_bounds__(256) void k_transform(const DrawItem* __restrict__ items,
-                                                   const uint32_t* __restrict__ vert_bases, FrameConst fc,
+                                                   const uint32_t* __restrict__ vert_bases, const FrameConst* __restrict__ fcp,
                                                    float4* __restrict__ clip, const uint32_t* __restrict__ vblock_needed,
                                                    const FrameCounters* __restrict__ counters) {
+    FrameConstRef fc = frame_const_ref(fcp);
     static_assert(kVertexBlock == 256, "one workgroup per vertex block");
     if (!vblock_needed[blockIdx.x] && !counters->all_verts) return;      // no surviving work unit reads this block
     uint32_t gid = blockIdx.x * 256u + threadIdx.x;
@@ -267,7 +281,7 @@ struct TileRect {
 
 // Cull + bbox + record of one snapped triangle.  Returns false when nothing can be covered.
 __device__ __forceinline__ bool make_record(const Snapped& a, const Snapped& b, const Snapped& c,
-                                            uint32_t tri_id, const FrameConst& fc, SetupRecord& r,
+                                            uint32_t tri_id, FrameConstRef fc, SetupRecord& r,
                                             TileRect& tr) {
     long long A2 = (long long)(b.x - a.x) * (c.y - a.y) - (long long)(c.x - a.x) * (b.y - a.y);
     long long area2 = -A2;
@@ -295,7 +309,7 @@ __device__ __forceinline__ uint32_t pack_tileword(const TileRect& t) {
     return t.tx0 | (t.ty0 << 8) | ((t.tx1 - t.tx0) << 16) | ((t.ty1 - t.ty0) << 24);
 }
 
-__device__ __forceinline__ bool any_owned(const TileRect& t, const FrameConst& fc) {
+__device__ __forceinline__ bool any_owned(const TileRect& t, FrameConstRef fc) {
     if (fc.world <= 1) return true;
     // rects spanning a whole ownership period in x or y always contain an owned tile
     if (t.ty1 - t.ty0 >= kOwnerGroup * fc.world) return true;
@@ -347,7 +361,7 @@ __device__ __forceinline__ f32x4 texture_sample(const TextureDesc& t, float u, f
 // textureSample(...); base.a < 0.5 discards), for draw items whose texture has alpha below 1.  Runs
 // in the raster stage, before the fragment may enter the (depth, id) resolve: the triangle's clip
 // positions and uv are fetched again from the id, barycentrics and the uv footprint as at shade time.
-__device__ __forceinline__ bool alpha_pass(const FrameBuffers& fb, const FrameConst& fc, uint32_t id, uint32_t i, uint32_t j) {
+__device__ __forceinline__ bool alpha_pass(const FrameBuffers& fb, FrameConstRef fc, uint32_t id, uint32_t i, uint32_t j) {
     const uint32_t it = find_item(fb.tri_bases, fc.n_items, id);
     const DrawItem& d = fb.items[it];
     const uint32_t tex = d.texture;
@@ -421,7 +435,7 @@ struct GlobalSink {
 
 template <bool kAlpha, class Sink>
 __device__ __forceinline__ void raster_small(const SetupRecord& r, int32_t i0, int32_t i1, int32_t j0, int32_t j1,
-                                             const Sink& sink, const FrameBuffers& fb, const FrameConst& fc) {
+                                             const Sink& sink, const FrameBuffers& fb, FrameConstRef fc) {
     // inside-positive edges: w0 = F(v2,v1,p), w1 = F(v0,v2,p), w2 = F(v1,v0,p)
     const int32_t ex0 = r.x1 - r.x2, ey0 = r.y1 - r.y2;
     const int32_t ex1 = r.x2 - r.x0, ey1 = r.y2 - r.y0;
@@ -461,7 +475,7 @@ __device__ __forceinline__ void raster_small(const SetupRecord& r, int32_t i0, i
 // Returns the in-bin position for single-tile records, kNoBinPos otherwise.
 constexpr uint32_t kNoBinPos = 0xFFFFFFFFu;
 
-__device__ __forceinline__ uint32_t count_wave(bool emit, const TileRect& t, const FrameConst& fc,
+__device__ __forceinline__ uint32_t count_wave(bool emit, const TileRect& t, FrameConstRef fc,
                                                uint32_t* __restrict__ count_single,
                                                uint32_t* __restrict__ count_multi, FrameCounters* counters) {
     const uint32_t lane = lane_id();
@@ -493,7 +507,7 @@ __device__ __forceinline__ uint32_t count_wave(bool emit, const TileRect& t, con
 // Reject / cull / snap / record of one triangle whose vertices need no clipping; sets need_clip
 // (and emits nothing) when it must go through the clipper.
 __device__ __forceinline__ void setup_triangle(const float4& c0, const float4& c1, const float4& c2, uint32_t gid,
-                                               const FrameConst& fc, float half_w, float half_h, SetupRecord& rec,
+                                               FrameConstRef fc, float half_w, float half_h, SetupRecord& rec,
                                                TileRect& tr, bool& emit, bool& need_clip) {
     bool finite = isfinite(c0.x) && isfinite(c0.y) && isfinite(c0.z) && isfinite(c0.w) &&
                   isfinite(c1.x) && isfinite(c1.y) && isfinite(c1.z) && isfinite(c1.w) &&
@@ -573,7 +587,7 @@ __device__ __forceinline__ DirectTri make_direct(const SetupRecord& r, const Til
 // pixel k (row-major in the bbox) of a compacted triangle
 template <bool kAlpha, class Sink>
 __device__ __forceinline__ void direct_pixel(const DirectTri& d, uint32_t k, const Sink& sink, const FrameBuffers& fb,
-                                             const FrameConst& fc) {
+                                             FrameConstRef fc) {
     const uint32_t w = d.shape & 255u;
     // k / w for k < 16, w <= 16: (k + 0.5) / w is at least 1/32 away from an integer, far beyond the
     // 1 ulp of the approximate reciprocal
@@ -606,7 +620,8 @@ constexpr uint32_t kSetupChunk = kChunkTris;
 // uniform for the whole workgroup, so its fields come in through scalar loads.
 // kAlpha: some draw item of the frame takes the per-fragment texture alpha test (compiled out otherwise)
 template <bool kAlpha>
-__global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, FrameConst fc, Capacities cap) {
+__global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) {
+    FrameConstRef fc = frame_const_ref(fb.frame_const);
     __shared__ uint32_t s_used;         // record slots of this workgroup's chunk handed out so far
     __shared__ uint32_t s_valid[4];
     __shared__ uint4 s_direct[4][64][5];   // per wave: the compacted small triangles of one iteration
@@ -742,7 +757,8 @@ __device__ __forceinline__ ClipVert clip_intersect(const ClipVert& in, float din
     return r;
 }
 
-__global__ __launch_bounds__(256) void k_clip(FrameBuffers fb, FrameConst fc, Capacities cap) {
+__global__ __launch_bounds__(256) void k_clip(FrameBuffers fb, Capacities cap) {
+    FrameConstRef fc = frame_const_ref(fb.frame_const);
     uint32_t n = min(fb.counters->n_clip, cap.clip_queue);
     for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < n; q += gridDim.x * 256u) {
         uint32_t gid = fb.clip_queue[q];
@@ -794,7 +810,8 @@ __global__ __launch_bounds__(256) void k_clip(FrameBuffers fb, FrameConst fc, Ca
 }
 
 // --- exclusive scan of the tile counts (one workgroup) --------------------------------------
-__global__ __launch_bounds__(1024) void k_scan_tiles(FrameBuffers fb, FrameConst fc, Capacities cap) {
+__global__ __launch_bounds__(1024) void k_scan_tiles(FrameBuffers fb, Capacities cap) {
+    FrameConstRef fc = frame_const_ref(fb.frame_const);
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_valid[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -867,7 +884,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(FrameBuffers fb, FrameConst
 }
 
 // --- K2b: scatter record slots into the bins ---------------------------------------------
-__device__ __forceinline__ void bin_record(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, uint32_t r) {
+__device__ __forceinline__ void bin_record(const FrameBuffers& fb, FrameConstRef fc, const Capacities& cap, uint32_t r) {
     const uint2 w = fb.tilewords[r];
     const uint32_t tx0 = w.x & 255u, ty0 = (w.x >> 8) & 255u;
     if (!guard(tx0 + ((w.x >> 16) & 255u) < fc.tiles_x && ty0 + (w.x >> 24) < fc.tiles_y, fb.counters, kGuardBin)) return;
@@ -893,7 +910,8 @@ __device__ __forceinline__ void bin_record(const FrameBuffers& fb, const FrameCo
 // the remaining workgroups stride over the clipper's records behind the deterministic slots.
 constexpr uint32_t kBinClipBlocks = 64;
 
-__global__ __launch_bounds__(256) void k_bin_fill(FrameBuffers fb, FrameConst fc, Capacities cap) {
+__global__ __launch_bounds__(256) void k_bin_fill(FrameBuffers fb, Capacities cap) {
+    FrameConstRef fc = frame_const_ref(fb.frame_const);
     const uint32_t n_chunks = fc.n_units;
     if (blockIdx.x < n_chunks) {
         if (blockIdx.x >= fb.counters->n_active) return;
@@ -917,7 +935,7 @@ __global__ __launch_bounds__(256) void k_bin_fill(FrameBuffers fb, FrameConst fc
 // ------------------------------------------------------------------------------------------
 template <bool kAlpha>
 __device__ __forceinline__ void raster_wave(const SetupRecord& r, int32_t i0, int32_t i1, int32_t j0, int32_t j1,
-                                            const LdsSink& sink, const FrameBuffers& fb, const FrameConst& fc) {
+                                            const LdsSink& sink, const FrameBuffers& fb, FrameConstRef fc) {
     const uint32_t lane = lane_id();
     const int32_t lx = (int32_t)(lane & 7u), ly = (int32_t)(lane >> 3);
     const int32_t ex0 = r.x1 - r.x2, ey0 = r.y1 - r.y2;
@@ -953,7 +971,8 @@ __device__ __forceinline__ SetupRecord load_record(const SetupRecord* __restrict
 }
 
 template <bool kAlpha>
-__global__ __launch_bounds__(256) void k_raster(FrameBuffers fb, FrameConst fc, Capacities cap) {
+__global__ __launch_bounds__(256) void k_raster(FrameBuffers fb, Capacities cap) {
+    FrameConstRef fc = frame_const_ref(fb.frame_const);
     __shared__ unsigned long long s_vis[kTilePixels];
     __shared__ uint32_t s_big[256];
     __shared__ uint32_t s_nbig;
@@ -1087,7 +1106,7 @@ struct PixelInputs {
 // `d` is wave-uniform (the caller waterfalls over the items of the wave), so its fields come in
 // through scalar loads; per pixel only the index triple and the three 32-byte vertices are gathered.
 template <bool kTextures>
-__device__ __forceinline__ void prepare_pixel(const DrawItem& d, const FrameConst& fc, const float4* __restrict__ clip,
+__device__ __forceinline__ void prepare_pixel(const DrawItem& d, FrameConstRef fc, const float4* __restrict__ clip,
                                               const TextureDesc* __restrict__ textures, uint32_t id, uint32_t i,
                                               uint32_t j, PixelInputs& o, FrameCounters* counters) {
     // straight-line: an index that would leave its buffer is clamped and reported, not branched on
@@ -1202,7 +1221,7 @@ __device__ __forceinline__ void prepare_pixel(const DrawItem& d, const FrameCons
 // through the cascade's matrix, 3x3 nearest taps (ClampToBorder, OpaqueWhite: depth 1 outside the
 // map, backend.rs:441-453).  The shader can select layer 3 although the uniform holds three
 // matrices (:118, :203): with naga's index clamping that layer is read through matrix 2.
-__device__ __forceinline__ float light_occlusion(const ShadowSet* __restrict__ sets, int32_t set, const FrameConst& fc,
+__device__ __forceinline__ float light_occlusion(const ShadowSet* __restrict__ sets, int32_t set, FrameConstRef fc,
                                                  float fx, float fy, float fz, float nx, float ny, float nz,
                                                  float lx, float ly, float lz) {
     if (set < 0) return 0.0f;
@@ -1249,7 +1268,7 @@ __device__ __forceinline__ float light_occlusion(const ShadowSet* __restrict__ s
 // fs_main_blinn_phong for one light and one fragment (render_mesh.wgsl:134-181, :256-281)
 template <bool kShadows>
 __device__ __forceinline__ void add_light(const GpuLight& L, PixelInputs& p, const ShadowSet* __restrict__ sets,
-                                          const FrameConst& fc) {
+                                          FrameConstRef fc) {
     float dx, dy, dz, intensity;
     if (L.kind == RND_LIGHT_DIRECTIONAL) {
         dx = L.dir[0]; dy = L.dir[1]; dz = L.dir[2];
@@ -1300,14 +1319,14 @@ __device__ __forceinline__ f32x2 splat2(float v) { return (f32x2){v, v}; }
 __device__ __forceinline__ f32x2 rsq2(f32x2 v) { return (f32x2){__builtin_amdgcn_rsqf(v.x), __builtin_amdgcn_rsqf(v.y)}; }
 __device__ __forceinline__ f32x2 max0(f32x2 v) { return (f32x2){fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f)}; }
 
-__device__ __forceinline__ float shadow_term(const ShadowSet* __restrict__ sets, const GpuLight& L, const FrameConst& fc,
+__device__ __forceinline__ float shadow_term(const ShadowSet* __restrict__ sets, const GpuLight& L, FrameConstRef fc,
                                              float fx, float fy, float fz, float nx, float ny, float nz) {
     return light_occlusion(sets, L.shadow_index, fc, fx, fy, fz, nx, ny, nz, L.dir[0], L.dir[1], L.dir[2]);
 }
 
 template <bool kShadows>
 __device__ __forceinline__ void add_light_pair(const GpuLight& L, PixelPair& p, const ShadowSet* __restrict__ sets,
-                                               const FrameConst& fc) {
+                                               FrameConstRef fc) {
 #pragma clang fp contract(fast)
     f32x2 dx, dy, dz, inten;
     if (L.kind == RND_LIGHT_DIRECTIONAL) {
@@ -1352,7 +1371,8 @@ __device__ __forceinline__ void add_light_pair(const GpuLight& L, PixelPair& p, 
 // and re-used while consecutive samples hold the same triangle — each sample keeps the f16 colour,
 // and the pixel gets their mean (the resolve attachment, visual_server.rs:1134-1153).
 template <int PPT, bool kShadows, int kSamples>
-__global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(FrameBuffers fb, FrameConst fc) {
+__global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(FrameBuffers fb) {
+    FrameConstRef fc = frame_const_ref(fb.frame_const);
     static_assert(kSamples == 1 || PPT == 1, "the MSAA variant shades one pixel per lane");
     __shared__ GpuLight s_lights[kMaxLights];
     __shared__ uint32_t s_bases[kLdsItems + 1];
@@ -1636,57 +1656,57 @@ __global__ void k_unpack(const unsigned long long* __restrict__ packed, FrameCon
 static inline uint32_t div_up(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
 
 void launch_clear(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream) {
-    hipLaunchKernelGGL(k_clear, dim3(fb.n_owned ? fb.n_owned : 1u), dim3(256), 0, stream, fb, fc);
+    hipLaunchKernelGGL(k_clear, dim3(fb.n_owned ? fb.n_owned : 1u), dim3(256), 0, stream, fb);
 }
 
 void launch_cull(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream) {
-    if (fc.n_units) hipLaunchKernelGGL(k_cull, dim3(div_up(fc.n_units, 256)), dim3(256), 0, stream, fb, fc);
+    if (fc.n_units) hipLaunchKernelGGL(k_cull, dim3(div_up(fc.n_units, 256)), dim3(256), 0, stream, fb);
 }
 
 void launch_transform(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream) {
     if (!fc.n_verts) return;
-    hipLaunchKernelGGL(k_transform, dim3(div_up(fc.n_verts, 256)), dim3(256), 0, stream, fb.items, fb.vert_bases, fc, fb.clip,
+    hipLaunchKernelGGL(k_transform, dim3(div_up(fc.n_verts, 256)), dim3(256), 0, stream, fb.items, fb.vert_bases, fb.frame_const, fb.clip,
                        fb.vblock_needed, fb.counters);
 }
 void launch_setup(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {
     if (!fc.n_tris) return;
-    if (fb.alpha_test) hipLaunchKernelGGL(k_setup<true>, dim3(fc.n_units), dim3(256), 0, stream, fb, fc, cap);
-    else hipLaunchKernelGGL(k_setup<false>, dim3(fc.n_units), dim3(256), 0, stream, fb, fc, cap);
+    if (fb.alpha_test) hipLaunchKernelGGL(k_setup<true>, dim3(fc.n_units), dim3(256), 0, stream, fb, cap);
+    else hipLaunchKernelGGL(k_setup<false>, dim3(fc.n_units), dim3(256), 0, stream, fb, cap);
 }
 void launch_clip(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {
     if (!fc.n_tris) return;
     uint32_t blocks = min(div_up(cap.clip_queue, 256), 1024u);
-    hipLaunchKernelGGL(k_clip, dim3(blocks), dim3(256), 0, stream, fb, fc, cap);
+    hipLaunchKernelGGL(k_clip, dim3(blocks), dim3(256), 0, stream, fb, cap);
 }
 void launch_scan(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, stream, fb, fc, cap);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, stream, fb, cap);
 }
 void launch_bin(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {
     if (!fc.n_tris) return;
     uint32_t blocks = fc.n_units + kBinClipBlocks;
-    hipLaunchKernelGGL(k_bin_fill, dim3(blocks), dim3(256), 0, stream, fb, fc, cap);
+    hipLaunchKernelGGL(k_bin_fill, dim3(blocks), dim3(256), 0, stream, fb, cap);
 }
 void launch_raster(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {
     if (!fb.n_owned) return;
-    if (fb.alpha_test) hipLaunchKernelGGL(k_raster<true>, dim3(fb.n_owned), dim3(256), 0, stream, fb, fc, cap);
-    else hipLaunchKernelGGL(k_raster<false>, dim3(fb.n_owned), dim3(256), 0, stream, fb, fc, cap);
+    if (fb.alpha_test) hipLaunchKernelGGL(k_raster<true>, dim3(fb.n_owned), dim3(256), 0, stream, fb, cap);
+    else hipLaunchKernelGGL(k_raster<false>, dim3(fb.n_owned), dim3(256), 0, stream, fb, cap);
 }
 void launch_shade(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream) {
     if (!fb.n_owned) return;
     static const int ppt = [] { const char* e = getenv("RND_SHADE_PPT"); int v = e ? atoi(e) : 2; return (v == 1 || v == 2 || v == 4) ? v : 1; }();
     const bool sh = fb.shadow_sets != nullptr || fb.has_textures;
     if (fc.n_samples == 4) {
-        if (sh) hipLaunchKernelGGL((k_shade<1, true, 4>), dim3(fb.n_owned * 4), dim3(256), 0, stream, fb, fc);
-        else hipLaunchKernelGGL((k_shade<1, false, 4>), dim3(fb.n_owned * 4), dim3(256), 0, stream, fb, fc);
+        if (sh) hipLaunchKernelGGL((k_shade<1, true, 4>), dim3(fb.n_owned * 4), dim3(256), 0, stream, fb);
+        else hipLaunchKernelGGL((k_shade<1, false, 4>), dim3(fb.n_owned * 4), dim3(256), 0, stream, fb);
     } else if (ppt == 4) {
-        if (sh) hipLaunchKernelGGL((k_shade<4, true, 1>), dim3(fb.n_owned), dim3(256), 0, stream, fb, fc);
-        else hipLaunchKernelGGL((k_shade<4, false, 1>), dim3(fb.n_owned), dim3(256), 0, stream, fb, fc);
+        if (sh) hipLaunchKernelGGL((k_shade<4, true, 1>), dim3(fb.n_owned), dim3(256), 0, stream, fb);
+        else hipLaunchKernelGGL((k_shade<4, false, 1>), dim3(fb.n_owned), dim3(256), 0, stream, fb);
     } else if (ppt == 2) {
-        if (sh) hipLaunchKernelGGL((k_shade<2, true, 1>), dim3(fb.n_owned * 2), dim3(256), 0, stream, fb, fc);
-        else hipLaunchKernelGGL((k_shade<2, false, 1>), dim3(fb.n_owned * 2), dim3(256), 0, stream, fb, fc);
+        if (sh) hipLaunchKernelGGL((k_shade<2, true, 1>), dim3(fb.n_owned * 2), dim3(256), 0, stream, fb);
+        else hipLaunchKernelGGL((k_shade<2, false, 1>), dim3(fb.n_owned * 2), dim3(256), 0, stream, fb);
     } else {
-        if (sh) hipLaunchKernelGGL((k_shade<1, true, 1>), dim3(fb.n_owned * 4), dim3(256), 0, stream, fb, fc);
-        else hipLaunchKernelGGL((k_shade<1, false, 1>), dim3(fb.n_owned * 4), dim3(256), 0, stream, fb, fc);
+        if (sh) hipLaunchKernelGGL((k_shade<1, true, 1>), dim3(fb.n_owned * 4), dim3(256), 0, stream, fb);
+        else hipLaunchKernelGGL((k_shade<1, false, 1>), dim3(fb.n_owned * 4), dim3(256), 0, stream, fb);
     }
 }
 void launch_extract(const uint64_t* vis, const TileRef* order, uint32_t n_owned, const FrameConst& fc, float* depth,

@@ -518,7 +518,21 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     const size_t off_li = align_up(off_ub + unit_bases.size() * 4, 256);
     const size_t off_si = align_up(off_li + lights.size() * sizeof(GpuLight), 256);
     const size_t off_ss = align_up(off_si + (n_sets ? shadow_items.size() * sizeof(DrawItem) : 0), 256);
-    const size_t total = align_up(off_ss + n_sets * sizeof(ShadowSet), 256) + 256;
+    // the constants of every pass of the frame: [0] main pass (sample 0), then one per shadow pass,
+    // then one per further MSAA sample
+    std::vector<FrameConst> consts(1 + n_passes + (msaa_ - 1), fc);
+    for (uint32_t k = 0; k < n_sets; ++k)
+        for (uint32_t c = 0; c < kShadowCascades; ++c) {
+            FrameConst& sfc = consts[1 + k * kShadowCascades + c];
+            lights_[shadowed[k]].cascades[c].to_cols_array(sfc.pv);
+            sfc.width = sfc.height = kShadowSize; sfc.tiles_x = sfc.tiles_y = kShadowSize / kTile;
+            sfc.rank = 0; sfc.world = 1; sfc.n_lights = 0;
+            sfc.n_samples = 1; sfc.sub_dx = sfc.sub_dy = 0;      // shadow maps are single-sampled (visual_server.rs:371)
+        }
+    for (uint32_t smp = 1; smp < msaa_; ++smp) sample_shift(smp, consts[n_passes + smp].sub_dx, consts[n_passes + smp].sub_dy);
+    constexpr size_t kConstSlot = (sizeof(FrameConst) + 255) / 256 * 256;
+    const size_t off_fc = align_up(off_ss + n_sets * sizeof(ShadowSet), 256);
+    const size_t total = off_fc + consts.size() * kConstSlot + 256;
     Staging& st = staging_[staging_next_];
     staging_next_ = (staging_next_ + 1) % 3;
     if (st.in_flight) { HIP_CHECK(hipEventSynchronize(st.done)); st.in_flight = false; }
@@ -538,6 +552,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
         std::memcpy(h + off_si, shadow_items.data(), shadow_items.size() * sizeof(DrawItem));
         std::memcpy(h + off_ss, sets.data(), n_sets * sizeof(ShadowSet));
     }
+    for (size_t k = 0; k < consts.size(); ++k) std::memcpy(h + off_fc + k * kConstSlot, &consts[k], sizeof(FrameConst));
     // one device block with the same layout, one copy (each hipMemcpyAsync costs the host ~8 us: with
     // a rank's share of a partitioned frame at ~0.13 ms of GPU time, the enqueue was the longer side)
     d_tables_.ensure(total + total / 2);
@@ -547,6 +562,8 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     st.in_flight = true;
 
     FrameBuffers fb{};
+    auto const_slot = [&](size_t k) { return reinterpret_cast<const FrameConst*>(tb + off_fc + k * kConstSlot); };
+    fb.frame_const = const_slot(0);
     fb.items = reinterpret_cast<const DrawItem*>(tb + off_items); fb.vert_bases = reinterpret_cast<const uint32_t*>(tb + off_vb);
     fb.tri_bases = reinterpret_cast<const uint32_t*>(tb + off_tb); fb.lights = reinterpret_cast<const GpuLight*>(tb + off_li);
     fb.textures = d_textures_.ptr;
@@ -592,11 +609,8 @@ void VisualServer::enqueue_frame(bool want_hdr) {
             sfb.launch_order = d_shadow_order_.ptr; sfb.n_owned = kShadowTiles;
             sfb.vis = shadow_layers_[k].ptr + (size_t)c * kShadowTiles * kTilePixels;
             sfb.frame_rgba8 = nullptr; sfb.tiles_rgba8 = nullptr; sfb.packed = nullptr; sfb.hdr = nullptr;
-            FrameConst sfc = fc;
-            lights_[shadowed[k]].cascades[c].to_cols_array(sfc.pv);
-            sfc.width = sfc.height = kShadowSize; sfc.tiles_x = sfc.tiles_y = kShadowSize / kTile;
-            sfc.rank = 0; sfc.world = 1; sfc.n_lights = 0;
-            sfc.n_samples = 1; sfc.sub_dx = sfc.sub_dy = 0;      // shadow maps are single-sampled (visual_server.rs:371)
+            const FrameConst& sfc = consts[1 + k * kShadowCascades + c];
+            sfb.frame_const = const_slot(1 + k * kShadowCascades + c);
             launch_clear(sfb, sfc, stream_);
             launch_cull(sfb, sfc, stream_);
             launch_transform(sfb, sfc, stream_);
@@ -625,8 +639,8 @@ void VisualServer::enqueue_frame(bool want_hdr) {
         FrameBuffers mfb = fb;
         mfb.vis = d_vis_.ptr + (size_t)smp * fb.vis_stride;
         mfb.counters = d_counters_.ptr + 1 + n_passes + (smp - 1);
-        FrameConst mfc = fc;
-        sample_shift(smp, mfc.sub_dx, mfc.sub_dy);
+        const FrameConst& mfc = consts[n_passes + smp];
+        mfb.frame_const = const_slot(n_passes + smp);
         launch_clear(mfb, mfc, stream_);
         launch_cull(mfb, mfc, stream_);
         launch_setup(mfb, mfc, cap_, stream_);
