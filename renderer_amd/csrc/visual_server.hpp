@@ -170,6 +170,12 @@ private:
     EventSet event_sets_[kEventSets];
     uint32_t event_next_ = 0;
     static constexpr uint64_t kTimingStride = 4;
+    // instantiated HIP graphs of the frame's kernel sequence, keyed by the launches' by-value arguments
+    static constexpr int kGraphSlots = 4;
+    struct CachedGraph { std::vector<uint8_t> key; hipGraphExec_t exec = nullptr; };
+    CachedGraph graphs_[kGraphSlots];
+    int graph_next_ = 0;
+    bool use_graphs_ = false;     // RND_GRAPH=1 turns them on (no gain measured on ROCm 7.2: hipGraphLaunch costs the host what the launches do)
     uint64_t frame_counter_ = 0;
     int last_set_ = -1;
     double timing_sum_[8] = {};
