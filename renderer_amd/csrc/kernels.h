@@ -48,7 +48,10 @@ struct FrameBuffers {
     float* hdr;                     // row-major f32 rgb (may be null; read-back only)
 };
 
-void launch_clear(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream);
+// host_tables/dev_tables/table_bytes (a multiple of 16): the frame's table block, copied by the first
+// clear of a frame from pinned host memory to the device; null/0 on the other passes' clears
+void launch_clear(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream, const void* host_tables = nullptr,
+                  void* dev_tables = nullptr, size_t table_bytes = 0);
 void launch_cull(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream);
 void launch_transform(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream);
 void launch_setup(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream);

@@ -140,9 +140,14 @@ __device__ __forceinline__ float4 clip_position(const DrawItem& d, FrameConstRef
 // its matrices come in through scalar loads.
 // ------------------------------------------------------------------------------------------
 // Frame clear: visibility words of the owned tiles to (depth 1.0, no triangle), tile counts and
-// frame counters to zero.  One workgroup per owned tile.
-__global__ __launch_bounds__(256) void k_clear(FrameBuffers fb) {
-    FrameConstRef fc = frame_const_ref(fb.frame_const);
+// frame counters to zero.  One workgroup per owned tile.  The first clear of a frame also brings in
+// the frame's tables: `n_vec` 16-byte words from the pinned host block `src` (read over the host
+// link by the kernel itself) to the device block `dst` that every later kernel of the frame reads.
+// That replaces a hipMemcpyAsync (a blit kernel of its own, ~3 us plus its dependency gaps per
+// frame).  The sizes come in as arguments: the frame's constants are part of what is being copied.
+__global__ __launch_bounds__(256) void k_clear(FrameBuffers fb, uint32_t n_counts, uint32_t n_vblocks,
+                                               const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t n_vec) {
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n_vec; k += gridDim.x * 256u) dst[k] = src[k];
     if (blockIdx.x < fb.n_owned) {
         const uint32_t tile = fb.launch_order[blockIdx.x].tile;
         typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
@@ -150,9 +155,7 @@ __global__ __launch_bounds__(256) void k_clear(FrameBuffers fb) {
         const u64x2 clear = {kClearKey, kClearKey};
         for (uint32_t k = threadIdx.x; k < kTilePixels / 2; k += 256u) dst[k] = clear;
     }
-    const uint32_t n_counts = 2u * fc.tiles_x * fc.tiles_y;
     for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n_counts; k += gridDim.x * 256u) fb.tile_count[k] = 0;
-    const uint32_t n_vblocks = (fc.n_verts + kVertexBlock - 1) / kVertexBlock;
     for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n_vblocks; k += gridDim.x * 256u) fb.vblock_needed[k] = 0;
     if (blockIdx.x == 0 && threadIdx.x < sizeof(FrameCounters) / 4) reinterpret_cast<uint32_t*>(fb.counters)[threadIdx.x] = 0;
 }
@@ -1655,8 +1658,15 @@ __global__ void k_unpack(const unsigned long long* __restrict__ packed, FrameCon
 // ------------------------------------------------------------------------------------------
 static inline uint32_t div_up(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
 
-void launch_clear(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream) {
-    hipLaunchKernelGGL(k_clear, dim3(fb.n_owned ? fb.n_owned : 1u), dim3(256), 0, stream, fb);
+void launch_clear(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream, const void* host_tables,
+                  void* dev_tables, size_t table_bytes) {
+    const uint32_t n_counts = 2u * fc.tiles_x * fc.tiles_y;
+    const uint32_t n_vblocks = (fc.n_verts + kVertexBlock - 1) / kVertexBlock;
+    const uint32_t n_vec = (uint32_t)(table_bytes / 16);
+    // enough workgroups for the table copy even when this context owns few tiles
+    const uint32_t blocks = std::max<uint32_t>(fb.n_owned ? fb.n_owned : 1u, std::min<uint32_t>(div_up(n_vec, 256), 1024u));
+    hipLaunchKernelGGL(k_clear, dim3(blocks), dim3(256), 0, stream, fb, n_counts, n_vblocks,
+                       static_cast<const uint4*>(host_tables), static_cast<uint4*>(dev_tables), n_vec);
 }
 
 void launch_cull(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream) {

@@ -542,7 +542,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     for (uint32_t smp = 1; smp < msaa_; ++smp) sample_shift(smp, consts[n_passes + smp].sub_dx, consts[n_passes + smp].sub_dy);
     constexpr size_t kConstSlot = (sizeof(FrameConst) + 255) / 256 * 256;
     const size_t off_fc = align_up(off_ss + n_sets * sizeof(ShadowSet), 256);
-    const size_t total = off_fc + consts.size() * kConstSlot + 256;
+    const size_t total = align_up(off_fc + consts.size() * kConstSlot + 256, 256);
     lap(0);
     Staging& st = staging_[staging_next_];
     staging_next_ = (staging_next_ + 1) % 3;
@@ -565,13 +565,10 @@ void VisualServer::enqueue_frame(bool want_hdr) {
         std::memcpy(h + off_ss, sets.data(), n_sets * sizeof(ShadowSet));
     }
     for (size_t k = 0; k < consts.size(); ++k) std::memcpy(h + off_fc + k * kConstSlot, &consts[k], sizeof(FrameConst));
-    // one device block with the same layout, one copy (each hipMemcpyAsync costs the host ~8 us: with
-    // a rank's share of a partitioned frame at ~0.13 ms of GPU time, the enqueue was the longer side)
+    // one device block with the same layout; the frame's first clear kernel copies it over from the
+    // pinned block (no hipMemcpyAsync: each one costs the host ~8 us and the GPU a blit kernel)
     d_tables_.ensure(total + total / 2);
-    HIP_CHECK(hipMemcpyAsync(d_tables_.ptr, h, total, hipMemcpyHostToDevice, stream_));
     uint8_t* const tb = d_tables_.ptr;
-    HIP_CHECK(hipEventRecord(st.done, stream_));
-    st.in_flight = true;
 
     lap(2);
     FrameBuffers fb{};
@@ -612,6 +609,12 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     }
     auto mark = [&](int k) { if (ev_) HIP_CHECK(hipEventRecord(ev_[k], stream_)); };
     auto emit = [&]() {
+    bool tables_pending = true;
+    auto clear = [&](const FrameBuffers& b, const FrameConst& c) {
+        if (tables_pending) launch_clear(b, c, stream_, h, tb, total);
+        else launch_clear(b, c, stream_);
+        tables_pending = false;
+    };
     // shadow cascades: depth-only passes of the same pipeline (cull, transform, setup, bins, raster)
     // into kShadowSize^2 visibility buffers, one per (directional light, cascade)
     mark(7);
@@ -625,7 +628,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
             sfb.frame_rgba8 = nullptr; sfb.tiles_rgba8 = nullptr; sfb.packed = nullptr; sfb.hdr = nullptr;
             const FrameConst& sfc = consts[1 + k * kShadowCascades + c];
             sfb.frame_const = const_slot(1 + k * kShadowCascades + c);
-            launch_clear(sfb, sfc, stream_);
+            clear(sfb, sfc);
             launch_cull(sfb, sfc, stream_);
             launch_transform(sfb, sfc, stream_);
             launch_setup(sfb, sfc, cap_, stream_);
@@ -635,7 +638,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
             launch_raster(sfb, sfc, cap_, stream_);
         }
     mark(0);
-    launch_clear(fb, fc, stream_);      // visibility words, tile counts, vertex-block flags, frame counters
+    clear(fb, fc);                      // visibility words, tile counts, vertex-block flags, frame counters
     launch_cull(fb, fc, stream_);       // work units that can reach the view volume and this context's stripes
     launch_transform(fb, fc, stream_);
     mark(1);
@@ -655,7 +658,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
         mfb.counters = d_counters_.ptr + 1 + n_passes + (smp - 1);
         const FrameConst& mfc = consts[n_passes + smp];
         mfb.frame_const = const_slot(n_passes + smp);
-        launch_clear(mfb, mfc, stream_);
+        clear(mfb, mfc);
         launch_cull(mfb, mfc, stream_);
         launch_setup(mfb, mfc, cap_, stream_);
         launch_clip(mfb, mfc, cap_, stream_);
@@ -685,7 +688,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
             add(dims, sizeof dims);
         }
         for (uint32_t k = 0; k < n_sets; ++k) { const void* p = shadow_layers_[k].ptr; add(&p, sizeof p); }
-        const void* ptrs[6] = {d_counters_.ptr, d_vis_.ptr, d_hdr_.ptr, d_present_.ptr, d_shadow_order_.ptr, tb};
+        const void* ptrs[8] = {d_counters_.ptr, d_vis_.ptr, d_hdr_.ptr, d_present_.ptr, d_shadow_order_.ptr, tb, h, reinterpret_cast<const void*>(total)};
         add(ptrs, sizeof ptrs);
         const uint64_t misc[10] = {off_si, off_fc, n_sets, msaa_, surface_w_, surface_h_, width_, height_, tone_mapping_, render_size_factor_ > 1.0f ? 1u : 0u};
         add(misc, sizeof misc);
@@ -720,7 +723,11 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     if (!launched) emit();
     lap(3);
     if (timed_set) timed_set->pending = true;
-    HIP_CHECK(hipMemcpyAsync(h_counters_, d_counters_.ptr, n_counter_sets_ * sizeof(FrameCounters), hipMemcpyDeviceToHost, stream_));
+    // the pinned block is free again once this frame's first kernel has read it; recorded after the
+    // whole sequence so that it also holds for a graph replay (three blocks rotate)
+    HIP_CHECK(hipEventRecord(st.done, stream_));
+    st.in_flight = true;
+    // the frame's counters come back in finish(): only a frame somebody waits for needs them
     HIP_CHECK(hipGetLastError());
     lap(4);
     if (prof && ++acc_n == 256) {
@@ -742,6 +749,7 @@ void VisualServer::finish() {
     use_device();
     uint32_t grew = 0;
     for (int attempt = 0; attempt < 8; ++attempt) {
+        HIP_CHECK(hipMemcpyAsync(h_counters_, d_counters_.ptr, n_counter_sets_ * sizeof(FrameCounters), hipMemcpyDeviceToHost, stream_));
         HIP_CHECK(hipStreamSynchronize(stream_));
         frame_pending_ = false;
         FrameCounters c = h_counters_[0];
