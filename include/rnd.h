@@ -166,6 +166,41 @@ int rnd_set_sprite(rnd_ctx* ctx, uint64_t id, const float transform_cols[16], ui
 /* reference: reset_scene :579-581 — drops meshes, materials, textures, lights, instances. */
 int rnd_reset_scene(rnd_ctx* ctx);
 
+/* ---- 2D overlay (reference: Pipeline2d, src/renderer/pipeline2d.rs:266-310) ---------- */
+/* The reference draws a second, surface-sized Rgba8UnormSrgb target every frame (cleared to
+ * transparent; visual_server.rs:110-118, :641-651): an optional full-screen debug view of a depth
+ * texture, then the UI boxes, then the texts, each alpha-blended in that order; Backend::render
+ * alpha-blends it over the presented 3D image (backend.rs:470-491).  All of it is per-pixel work
+ * on the final frame and runs as one more kernel after shading, only when something is set. */
+/* reference: UiBoxInstance, src/renderer/pipeline2d/uibox_instance.rs:5-11 (#[repr(C)], 32 B);
+ * position = top-left corner in surface pixels (y down), colour is gamma 2.2 encoded (uibox.wgsl:27) */
+typedef struct rnd_uibox {
+    float position[2];
+    float size[2];
+    float color[4];
+} rnd_uibox;
+/* reference: set_uiboxes(&[UiBoxInstance]) visual_server.rs:476-479 — replaces the list */
+int rnd_set_uiboxes(rnd_ctx* ctx, uint32_t n, const rnd_uibox* boxes);
+/* reference: set_font_image(Handle<Image>, ..) :192-204 — a wide atlas of 128 monospaced glyph
+ * cells holding a signed distance field (text.wgsl:53-63, :76-105), RGBA8 sampled as Rgba8Unorm
+ * (linear, one level; backend.rs:385-412) with the Repeat + linear sampler.  Default: the 1x1
+ * (255,255,0,255) texture (:82). */
+int rnd_set_font_image(rnd_ctx* ctx, uint32_t width, uint32_t height, const uint8_t* rgba8);
+/* reference: reset_texts :552-554, add_text(NodeId, TextDescriptor{text, position, font_size})
+ * :556-577 — one glyph quad per byte (ids above 127 become 127), advance font_size*1.1667*0.5 */
+int rnd_reset_texts(rnd_ctx* ctx);
+int rnd_add_text(rnd_ctx* ctx, const uint8_t* text, uint32_t n_bytes, float x, float y, float font_size);
+/* reference: set_depth_fullscreen_texture :313-326, set_shadow_map_fullscreen_texture(light) :328-346
+ * (layer 0 of the light's cascade maps; an unknown light leaves the setting as it is, as the
+ * reference's warning path does), unset_fullscreen_texture :348-350; fullscreen_texture.wgsl shows
+ * (2*0.5)/(50.5 - d*49.5) as grey.  rnd_reset_scene also unsets it (it lives in RenderScene, :903). */
+int rnd_set_depth_fullscreen_texture(rnd_ctx* ctx);
+int rnd_set_shadow_map_fullscreen_texture(rnd_ctx* ctx, uint64_t light_id);
+int rnd_unset_fullscreen_texture(rnd_ctx* ctx);
+/* the 2D target of the last frame, RGBA8 (sRGB-encoded colour, linear alpha), render_size; all
+ * zero when nothing 2D is set.  No counterpart in the reference. */
+int rnd_read_overlay_rgba8(rnd_ctx* ctx, uint8_t* dst);
+
 /* ---- frame ------------------------------------------------------------------------- */
 /* reference: VisualServer::render :224-311 (+ Pipeline3d::render, Backend::render).
  * Enqueues the whole frame on the context's stream and returns; rnd_finish waits for it. */

@@ -292,8 +292,17 @@ struct Ctx {
     M4 inv_pv = identity();            // RenderScene::inv_projection_view (Default = identity), visual_server.rs:898
     float ambient[4] = {0.3f, 0.5f, 0.9f, 0.04f};             // visual_server.rs:67
 
+    // 2D overlay state (Pipeline2d): boxes, glyph quads of every text, font atlas, debug view
+    struct Glyph { float pos[2], scale[2]; uint32_t glyph; };      // GlyphInstance, pipeline2d/glyph_instance.rs:5-9
+    std::vector<rnd_uibox> uiboxes;
+    std::vector<Glyph> glyphs;
+    Texture font;                       // Rgba8Unorm (linear), one level
+    int fullscreen = 0;                 // 0 none, 1 depth of the 3D target, 2 layer 0 of a light's shadow maps
+    uint64_t fullscreen_light = 0;
+
     // frame outputs
     bool have_frame = false;
+    std::vector<uint8_t> overlay;       // the 2D target, SW x SH RGBA8
     std::vector<uint64_t> vis;
     std::vector<float> hdr;
     std::vector<uint8_t> rgba;
@@ -622,6 +631,147 @@ static int build_items(Ctx& c, std::vector<DrawItem>& items) {
     return RND_OK;
 }
 
+// ------------------------------------------------------------------------------------
+// 2D overlay (DESIGN.md raster rule 14).  Pipeline2d::render (pipeline2d.rs:266-310) draws into a
+// surface-sized Rgba8UnormSrgb target cleared to transparent: the full-screen debug view, the UI
+// boxes, the texts, all with BlendState::ALPHA_BLENDING (rgb = s.rgb*s.a + d.rgb*(1-s.a),
+// a = s.a + d.a*(1-s.a)); Backend::render (backend.rs:470-491) then draws that target over the
+// presented 3D image with the same blend state.  A fixed-point target clamps the source to [0,1]
+// before blending and stores 8 bits after every draw, so the destination is re-decoded each time.
+// Quads are instanced 4-vertex strips, axis-aligned: the two triangles share the diagonal and the
+// top-left rule gives every pixel centre in [left, right) x [top, bottom) to exactly one of them.
+// ------------------------------------------------------------------------------------
+static const float* srgb_decode_lut() {
+    static float lut[256];
+    static bool init = false;
+    if (!init) {
+        for (int v = 0; v < 256; ++v) {
+            double x = v / 255.0;
+            lut[v] = (float)(x <= 0.04045 ? x / 12.92 : std::pow((x + 0.055) / 1.055, 2.4));
+        }
+        init = true;
+    }
+    return lut;
+}
+
+static inline float sat(float x) { return std::fmin(std::fmax(x, 0.0f), 1.0f); }     // NaN -> 0
+static inline float smoothstep(float e0, float e1, float x) {
+    float t = sat((x - e0) / (e1 - e0));
+    return (t * t) * (3.0f - 2.0f * t);
+}
+
+// ALPHA_BLENDING of src (linear rgb, alpha) onto an Rgba8UnormSrgb texel
+static inline void blend_srgb8(uint8_t d[4], const float src[4]) {
+    const float* lut = srgb_decode_lut();
+    const float a = sat(src[3]);
+    for (int k = 0; k < 3; ++k) d[k] = srgb8(sat(src[k]) * a + lut[d[k]] * (1.0f - a));
+    const float oa = a * 1.0f + ((float)d[3] / 255.0f) * (1.0f - a);
+    d[3] = (uint8_t)(int)(sat(oa) * 255.0f + 0.5f);
+}
+
+// An instanced quad after the vertex stage (uibox.wgsl:30-42, text.wgsl:39-51): the corner
+// (cx, cy) in {0,1}^2 sits at pos + c*size with y measured from the top, goes to clip space and
+// through the viewport transform, and is snapped like any other vertex (rule 2).
+struct Quad2D { int32_t xa, xb, yt, yb; };
+static Quad2D quad_2d(const float pos[2], const float size[2], uint32_t SW, uint32_t SH) {
+    const float vw = (float)SW, vh = (float)SH, half_w = 0.5f * vw, half_h = 0.5f * vh;
+    auto snap_x = [&](float cx) {
+        float tp = cx * size[0] + pos[0];
+        float clip = (tp / vw) * 2.0f - 1.0f;
+        float sx = (clip + 1.0f) * half_w;
+        return (int32_t)std::fmin(std::fmax(std::nearbyint(sx * (float)SUB), -1.0e9f), 1.0e9f);
+    };
+    auto snap_y = [&](float cy) {
+        float tp = cy * size[1] + ((vh - pos[1]) - size[1]);
+        float clip = (tp / vh) * 2.0f - 1.0f;
+        float sy = (1.0f - clip) * half_h;
+        return (int32_t)std::fmin(std::fmax(std::nearbyint(sy * (float)SUB), -1.0e9f), 1.0e9f);
+    };
+    return Quad2D{snap_x(0.0f), snap_x(1.0f), snap_y(1.0f), snap_y(0.0f)};
+}
+// front-facing (counter-clockwise, cull Back: pipeline2d.rs:465-470) and covering the centre of (i, j);
+// u, v = the quad's own 0..1 coordinates there (v = 0 at the top: text.wgsl:54-57)
+static inline bool quad_covers(const Quad2D& q, uint32_t i, uint32_t j, float& u, float& v) {
+    const int64_t area = (int64_t)(q.xb - q.xa) * (int64_t)(q.yb - q.yt);
+    if (area <= 0) return false;
+    const int32_t px = (int32_t)i * SUB + SUB / 2, py = (int32_t)j * SUB + SUB / 2;
+    if (px < std::min(q.xa, q.xb) || px >= std::max(q.xa, q.xb) || py < std::min(q.yt, q.yb) || py >= std::max(q.yt, q.yb)) return false;
+    u = (float)(px - q.xa) / (float)(q.xb - q.xa);
+    v = (float)(py - q.yt) / (float)(q.yb - q.yt);
+    return true;
+}
+
+static void render_overlay(Ctx& c) {
+    const uint32_t SW = c.SW, SH = c.SH;
+    c.overlay.assign((size_t)SW * SH * 4, 0);
+    if (!c.fullscreen && c.uiboxes.empty() && c.glyphs.empty()) return;
+    struct Box { Quad2D q; float color[4]; };
+    std::vector<Box> boxes;
+    for (const rnd_uibox& b : c.uiboxes) {
+        Box o; o.q = quad_2d(b.position, b.size, SW, SH);
+        for (int k = 0; k < 3; ++k) o.color[k] = std::pow(b.color[k], 2.2f);      // uibox.wgsl:27-28
+        o.color[3] = b.color[3];
+        boxes.push_back(o);
+    }
+    std::vector<Quad2D> gq;
+    for (const Ctx::Glyph& g : c.glyphs) gq.push_back(quad_2d(g.pos, g.scale, SW, SH));
+    // the debug view's source: depth of the 3D target (sample 0) or layer 0 of a light's cascade maps
+    const std::vector<float>* shadow0 = nullptr;
+    if (c.fullscreen == 2)
+        for (const Light& l : c.lights)
+            if (l.id == c.fullscreen_light && !l.shadow.empty()) shadow0 = &l.shadow[0];
+    const float* lut = srgb_decode_lut();
+    parallel_for(c.threads, SH, [&](size_t lo, size_t hi) {
+        for (size_t j = lo; j < hi; ++j)
+            for (uint32_t i = 0; i < SW; ++i) {
+                if (c.world > 1 && !owns_pixel(c, i, (uint32_t)j)) continue;
+                uint8_t* d = &c.overlay[((size_t)j * SW + i) * 4];
+                if (c.fullscreen) {
+                    // fullscreen_texture.wgsl: uv of the pixel centre, nearest + ClampToEdge sampler
+                    const float u = ((float)i + 0.5f) / (float)SW, v = ((float)j + 0.5f) / (float)SH;
+                    float depth = 1.0f;
+                    if (c.fullscreen == 1) {
+                        uint32_t x = std::min((uint32_t)std::floor(u * (float)c.W), c.W - 1), y = std::min((uint32_t)std::floor(v * (float)c.H), c.H - 1);
+                        depth = bitsf((uint32_t)(c.vis[(size_t)y * c.W + x] >> 32));
+                    } else if (shadow0) {
+                        uint32_t x = std::min((uint32_t)std::floor(u * (float)SHADOW_DIM), SHADOW_DIM - 1), y = std::min((uint32_t)std::floor(v * (float)SHADOW_DIM), SHADOW_DIM - 1);
+                        depth = (*shadow0)[(size_t)y * SHADOW_DIM + x];
+                    }
+                    const float dd = (2.0f * 0.5f) / ((50.0f + 0.5f) - depth * (50.0f - 0.5f));     // linearize_depth :37-42
+                    const float src[4] = {dd, dd, dd, 1.0f};
+                    blend_srgb8(d, src);
+                }
+                float u, v;
+                for (const Box& b : boxes)
+                    if (quad_covers(b.q, i, (uint32_t)j, u, v)) blend_srgb8(d, b.color);
+                for (size_t k = 0; k < gq.size(); ++k) {
+                    if (!quad_covers(gq[k], i, (uint32_t)j, u, v)) continue;
+                    const Ctx::Glyph& g = c.glyphs[k];
+                    // text.wgsl:58-65: the glyph's cell of the atlas; :76-105: signed distance field
+                    const float cell = 1.0f / 128.0f;
+                    const float u0 = (0.0f / 128.0f) + (float)g.glyph * cell, u1 = (1.0f / 128.0f) + (float)g.glyph * cell;
+                    const float tu = u0 + (u1 - u0) * u;
+                    float sd[4];
+                    bilinear(c.font, 0, tu, v, sd);
+                    const float ratio = (g.scale[1] - 12.0f) / (24.0f - 12.0f);
+                    const float smoothing = std::fmin(std::fmax(0.25f + ratio * (0.15f - 0.25f), 0.1f), 0.9f);
+                    const float fill_dist = smoothstep(0.37f - smoothing, 0.37f + smoothing, sd[2]);
+                    const float outline_dist = smoothstep(0.8f - smoothing, 0.8f + smoothing, sd[2]);
+                    const float fill_alpha = 1.0f - fill_dist, alpha = 1.0f - outline_dist;
+                    const float col = 0.0f * (1.0f - fill_alpha) + 1.0f * fill_alpha;              // mix(outline, fill, fill_alpha)
+                    const float src[4] = {col, col, col, alpha};
+                    blend_srgb8(d, src);
+                }
+                // Backend::render: the 2D target over the presented 3D image (filtered sampler at the
+                // surface's own resolution = the texel itself), ALPHA_BLENDING onto the sRGB surface
+                if (d[3] == 0) continue;        // s.a = 0 leaves the surface texel as it is
+                uint8_t* f = &c.rgba[((size_t)j * SW + i) * 4];
+                const float a = (float)d[3] / 255.0f;
+                for (int k = 0; k < 3; ++k) f[k] = srgb8(lut[d[k]] * a + lut[f[k]] * (1.0f - a));
+            }
+    });
+}
+
 static int render(Ctx& c) {
     auto t_begin = std::chrono::steady_clock::now();
     const uint32_t W = c.W, H = c.H;
@@ -885,6 +1035,8 @@ static int render(Ctx& c) {
         });
     }
 
+    render_overlay(c);
+
     auto t_end = std::chrono::steady_clock::now();
     c.timings = rnd_timings{};
     c.timings.frame_ms = std::chrono::duration<float, std::milli>(t_end - t_begin).count();
@@ -909,6 +1061,14 @@ static orc::M4 load_m4(const float* p) { orc::M4 m; std::memcpy(m.c, p, 64); ret
 
 extern "C" {
 
+static void set_font(Ctx* c, uint32_t w, uint32_t h, const uint8_t* data) {
+    orc::Texture t;
+    t.w = w; t.h = h; t.mips = 1; t.opaque = false;
+    t.level_offset.push_back(0);
+    t.texels.resize((size_t)w * h * 4);
+    for (size_t k = 0; k < (size_t)w * h * 4; ++k) t.texels[k] = (float)(data[k] / 255.0);     // Rgba8Unorm
+    c->font = std::move(t);
+}
 int orc_create(rnd_ctx** out, uint32_t width, uint32_t height, int /*device*/) {
     if (!out || width == 0 || height == 0 || width > 16384 || height > 16384) {
         g_create_err = "orc_create: bad size";
@@ -917,6 +1077,8 @@ int orc_create(rnd_ctx** out, uint32_t width, uint32_t height, int /*device*/) {
     Ctx* c = new Ctx();
     c->W = c->SW = width; c->H = c->SH = height;
     c->meshes[orc::QUAD_MESH_ID] = orc::quad_mesh();
+    const uint8_t yellow[4] = {255, 255, 0, 255};      // visual_server.rs:82
+    set_font(c, 1, 1, yellow);
     *out = reinterpret_cast<rnd_ctx*>(c);
     return RND_OK;
 }
@@ -1052,14 +1214,50 @@ int orc_reset_scene(rnd_ctx* ctx) {
     c->meshes.clear(); c->materials.clear(); c->textures.clear(); c->lights.clear(); c->instances.clear();
     c->sprite_material.clear();
     c->meshes[orc::QUAD_MESH_ID] = orc::quad_mesh();
+    c->fullscreen = 0;          // RenderScene::fullscreen_texture (visual_server.rs:903)
     return RND_OK;
 }
+
+int orc_set_uiboxes(rnd_ctx* ctx, uint32_t n, const rnd_uibox* boxes) {
+    Ctx* c = CTX(ctx);
+    if (n && !boxes) { c->err = "null boxes"; return RND_ERR_INVALID; }
+    c->uiboxes.assign(boxes, boxes + n);
+    return RND_OK;
+}
+int orc_set_font_image(rnd_ctx* ctx, uint32_t w, uint32_t h, const uint8_t* data) {
+    Ctx* c = CTX(ctx);
+    if (!w || !h || !data || w > 16384 || h > 16384) { c->err = "bad font image"; return RND_ERR_INVALID; }
+    set_font(c, w, h, data);
+    return RND_OK;
+}
+int orc_reset_texts(rnd_ctx* ctx) { CTX(ctx)->glyphs.clear(); return RND_OK; }
+int orc_add_text(rnd_ctx* ctx, const uint8_t* text, uint32_t n, float x, float y, float font_size) {
+    Ctx* c = CTX(ctx);
+    if (n && !text) { c->err = "null text"; return RND_ERR_INVALID; }
+    for (uint32_t i = 0; i < n; ++i) {          // visual_server.rs:556-570
+        Ctx::Glyph g;
+        g.pos[0] = x + (float)i * font_size * 1.1667f * 0.5f; g.pos[1] = y + 0.0f;
+        g.scale[0] = font_size * 1.1667f * 0.5f; g.scale[1] = font_size;
+        g.glyph = std::min<uint32_t>(text[i], 127u);
+        c->glyphs.push_back(g);
+    }
+    return RND_OK;
+}
+int orc_set_depth_fullscreen_texture(rnd_ctx* ctx) { CTX(ctx)->fullscreen = 1; return RND_OK; }
+int orc_set_shadow_map_fullscreen_texture(rnd_ctx* ctx, uint64_t light_id) {
+    Ctx* c = CTX(ctx);
+    for (const auto& l : c->lights)
+        if (l.id == light_id) { c->fullscreen = 2; c->fullscreen_light = light_id; return RND_OK; }
+    return RND_OK;      // "warning: no such light registered" and return (visual_server.rs:329-332)
+}
+int orc_unset_fullscreen_texture(rnd_ctx* ctx) { CTX(ctx)->fullscreen = 0; return RND_OK; }
 
 int orc_render(rnd_ctx* ctx) { return orc::render(*CTX(ctx)); }
 int orc_finish(rnd_ctx*) { return RND_OK; }
 
 #define NEED_FRAME(c) if (!(c)->have_frame) { (c)->err = "no frame rendered yet"; return RND_ERR_NO_FRAME; }
 int orc_read_color_rgba8(rnd_ctx* ctx, uint8_t* dst) { Ctx* c = CTX(ctx); NEED_FRAME(c); std::memcpy(dst, c->rgba.data(), c->rgba.size()); return RND_OK; }
+int orc_read_overlay_rgba8(rnd_ctx* ctx, uint8_t* dst) { Ctx* c = CTX(ctx); NEED_FRAME(c); std::memcpy(dst, c->overlay.data(), c->overlay.size()); return RND_OK; }
 int orc_read_color_hdr(rnd_ctx* ctx, float* dst) { Ctx* c = CTX(ctx); NEED_FRAME(c); std::memcpy(dst, c->hdr.data(), c->hdr.size() * 4); return RND_OK; }
 int orc_read_depth(rnd_ctx* ctx, float* dst) {
     Ctx* c = CTX(ctx); NEED_FRAME(c);

@@ -61,6 +61,11 @@ class FrameStats(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class UiBox(C.Structure):
+    """reference: UiBoxInstance, src/renderer/pipeline2d/uibox_instance.rs:5-11"""
+    _fields_ = [("position", C.c_float * 2), ("size", C.c_float * 2), ("color", C.c_float * 4)]
+
+
 _F16 = C.POINTER(C.c_float)
 _P = C.c_void_p
 
@@ -88,6 +93,14 @@ SIGNATURES = {
     "set_mesh_instance_ex": (C.c_int, [_P, C.c_uint64, _F16, C.c_uint32, C.c_uint32, C.c_uint32]),
     "set_sprite": (C.c_int, [_P, C.c_uint64, _F16, C.c_uint32, _F16]),
     "reset_scene": (C.c_int, [_P]),
+    "set_uiboxes": (C.c_int, [_P, C.c_uint32, _P]),
+    "set_font_image": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P]),
+    "reset_texts": (C.c_int, [_P]),
+    "add_text": (C.c_int, [_P, _P, C.c_uint32, C.c_float, C.c_float, C.c_float]),
+    "set_depth_fullscreen_texture": (C.c_int, [_P]),
+    "set_shadow_map_fullscreen_texture": (C.c_int, [_P, C.c_uint64]),
+    "unset_fullscreen_texture": (C.c_int, [_P]),
+    "read_overlay_rgba8": (C.c_int, [_P, _P]),
     "render": (C.c_int, [_P]),
     "finish": (C.c_int, [_P]),
     "read_color_rgba8": (C.c_int, [_P, _P]),

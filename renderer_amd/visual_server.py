@@ -189,6 +189,47 @@ class VisualServer:
         self._material_ids.clear()
         self._texture_ids.clear()
 
+    # -- 2D overlay (pipeline2d.rs) ------------------------------------------------------
+    def set_uiboxes(self, uiboxes):
+        """visual_server.rs:476-479; uiboxes: iterable of (position xy, size xy, Color or rgba)"""
+        rows = []
+        for pos, size, color in uiboxes:
+            col = color.to_array() if hasattr(color, "to_array") else color
+            rows.append([pos[0], pos[1], size[0], size[1], col[0], col[1], col[2], col[3]])
+        arr = np.ascontiguousarray(np.asarray(rows, dtype=np.float32).reshape(-1, 8))
+        self._check(self.api.set_uiboxes(self._ctx, len(rows), arr.ctypes.data if len(rows) else None))
+
+    def set_font_image(self, image_handle, asset_server=None):
+        """visual_server.rs:192-204"""
+        if asset_server is not None:
+            self.asset_server = asset_server
+        image = self.asset_server.get(image_handle)
+        data = np.ascontiguousarray(image.data, dtype=np.uint8)
+        self._check(self.api.set_font_image(self._ctx, int(image.width), int(image.height), data.ctypes.data))
+
+    def reset_texts(self):
+        """visual_server.rs:552-554"""
+        self._check(self.api.reset_texts(self._ctx))
+
+    def add_text(self, id, text, position, font_size):
+        """visual_server.rs:556-577 (TextDescriptor{text, position, font_size}); `id` is unused there too"""
+        raw = text.encode("latin-1") if isinstance(text, str) else bytes(text)
+        buf = np.frombuffer(raw, dtype=np.uint8) if raw else np.zeros(0, np.uint8)
+        self._check(self.api.add_text(self._ctx, buf.ctypes.data if len(buf) else None, len(buf),
+                                      float(position[0]), float(position[1]), float(font_size)))
+
+    def set_depth_fullscreen_texture(self):
+        """visual_server.rs:313-326"""
+        self._check(self.api.set_depth_fullscreen_texture(self._ctx))
+
+    def set_shadow_map_fullscreen_texture(self, light_id):
+        """visual_server.rs:328-346"""
+        self._check(self.api.set_shadow_map_fullscreen_texture(self._ctx, int(light_id)))
+
+    def unset_fullscreen_texture(self):
+        """visual_server.rs:348-350"""
+        self._check(self.api.unset_fullscreen_texture(self._ctx))
+
     # -- frame ---------------------------------------------------------------------------
     def render(self):
         """visual_server.rs:224-311 — enqueues the frame; read-backs wait for it."""
@@ -206,6 +247,10 @@ class VisualServer:
     def read_color_rgba8(self):
         w, h = self.render_size()
         return self._read(self.api.read_color_rgba8, (h, w, 4), np.uint8)
+
+    def read_overlay_rgba8(self):
+        w, h = self.render_size()
+        return self._read(self.api.read_overlay_rgba8, (h, w, 4), np.uint8)
 
     def read_color_hdr(self):
         w, h = self.render_resolution()
