@@ -143,6 +143,20 @@ int rnd_set_sprite(rnd_ctx* ctx, uint64_t id, const float t[16], uint32_t textur
 }
 int rnd_reset_scene(rnd_ctx* ctx) { return guard(ctx, [&](rnd::VisualServer& v) { v.reset_scene(); }); }
 
+int rnd_set_uiboxes(rnd_ctx* ctx, uint32_t n, const rnd_uibox* boxes) { return guard(ctx, [&](rnd::VisualServer& v) { v.set_uiboxes(n, boxes); }); }
+int rnd_set_font_image(rnd_ctx* ctx, uint32_t w, uint32_t h, const uint8_t* rgba8) { return guard(ctx, [&](rnd::VisualServer& v) { v.set_font_image(w, h, rgba8); }); }
+int rnd_reset_texts(rnd_ctx* ctx) { return guard(ctx, [&](rnd::VisualServer& v) { v.reset_texts(); }); }
+int rnd_add_text(rnd_ctx* ctx, const uint8_t* text, uint32_t n, float x, float y, float font_size) {
+    return guard(ctx, [&](rnd::VisualServer& v) { v.add_text(text, n, x, y, font_size); });
+}
+int rnd_set_depth_fullscreen_texture(rnd_ctx* ctx) { return guard(ctx, [&](rnd::VisualServer& v) { v.set_depth_fullscreen_texture(); }); }
+int rnd_set_shadow_map_fullscreen_texture(rnd_ctx* ctx, uint64_t light_id) { return guard(ctx, [&](rnd::VisualServer& v) { v.set_shadow_map_fullscreen_texture(light_id); }); }
+int rnd_unset_fullscreen_texture(rnd_ctx* ctx) { return guard(ctx, [&](rnd::VisualServer& v) { v.unset_fullscreen_texture(); }); }
+int rnd_read_overlay_rgba8(rnd_ctx* ctx, uint8_t* dst) {
+    REQUIRE(ctx, dst, "null destination");
+    return guard(ctx, [&](rnd::VisualServer& v) { v.read_overlay_rgba8(dst); });
+}
+
 int rnd_render(rnd_ctx* ctx) { return guard(ctx, [&](rnd::VisualServer& v) { v.render(); }); }
 int rnd_finish(rnd_ctx* ctx) { return guard(ctx, [&](rnd::VisualServer& v) { v.finish(); }); }
 

@@ -126,6 +126,33 @@ struct SetupRecord {
 static_assert(sizeof(SetupRecord) == 48, "SetupRecord is 3 x 16 bytes");
 
 // Device-side counters of one frame.
+// ---- 2D overlay (pipeline2d.rs) --------------------------------------------------------------
+// One instanced quad of the 2D pass after its vertex stage: a UI box (uibox.wgsl) or a glyph (text.wgsl).
+struct Prim2D {
+    int32_t xa, xb, yt, yb;       // snapped corners (1/256 px): x at quad u = 0 / 1, y at the top (v = 0) / bottom
+    float color[4];               // box: pow(rgb, 2.2), alpha
+    uint32_t kind;                // 0 box, 1 glyph
+    uint32_t glyph;               // atlas cell 0..127
+    float font_size;
+    uint32_t pad;
+};
+static_assert(sizeof(Prim2D) == 48, "Prim2D layout");
+
+struct OverlayParams {
+    const Prim2D* prims;          // boxes first, then the glyphs of every text, in draw order
+    const float* srgb_lut;        // 256 entries: sRGB8 -> linear
+    TextureDesc font;             // RGBA f32, one level (Rgba8Unorm)
+    const uint64_t* depth_src;               // debug view: tile-major (depth bits << 32 | id) words, or null
+    uint32_t n_prims;
+    uint32_t fullscreen;          // 0 none, 1 depth of the 3D target, 2 a shadow map
+    uint32_t src_w, src_h, src_tiles_x;
+    uint32_t sw, sh, tiles_x;     // surface size and its tiles per row
+    uint32_t rank, world;
+    uint32_t* frame;              // row-major surface RGBA8, or null on a tile partition
+    uint32_t* tiles;              // this context's compact tile-major RGBA8 on a tile partition
+    uint32_t* overlay_out;        // row-major surface-sized 2D target
+};
+
 struct FrameCounters {
     uint32_t n_records;        // setup records written by the clipper (after the deterministic slots)
     uint32_t n_clip;           // triangles queued for the clipper

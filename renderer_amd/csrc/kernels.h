@@ -79,6 +79,8 @@ void launch_detile_gathered(const uint8_t* gathered, uint64_t stride_bytes, uint
 void launch_present(const float* hdr, uint32_t w, uint32_t h, uint8_t* frame_rgba8, uint32_t sw, uint32_t sh,
                     bool linear, uint32_t tone, hipStream_t stream);
 // packed (depth | rgba8) row-major -> RGBA8 frame + tile-major vis depth
+// n_tiles = tiles of the surface (32x32); workgroups of tiles another rank owns return at once
+void launch_overlay(const OverlayParams& p, uint32_t n_tiles, hipStream_t stream);
 void launch_unpack(const uint64_t* packed, const FrameConst& fc, uint8_t* frame_rgba8, float* depth,
                    hipStream_t stream);
 

@@ -1614,6 +1614,128 @@ __global__ void k_detile_gathered(const uint32_t* __restrict__ gathered, uint64_
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// 2D overlay (raster rule 14; pipeline2d.rs:266-310, backend.rs:470-491).  One workgroup per 32x32
+// tile of the surface, four pixels per lane.  Per pixel the Rgba8UnormSrgb 2D target starts
+// transparent and takes, in draw order, the debug view, the boxes and the glyphs that cover the
+// pixel centre, each with ALPHA_BLENDING and an 8-bit store; the result goes over the presented
+// frame with the same blend.  Quads are axis-aligned, so coverage is a half-open interval test on
+// the snapped corners.  The quads of a batch of 256 that touch the tile are compacted, in order,
+// into LDS (ballot + prefix) before the pixels walk them.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sat_f(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+__device__ __forceinline__ float smoothstep_f(float e0, float e1, float x) {
+    const float t = sat_f((x - e0) / (e1 - e0));
+    return (t * t) * (3.0f - 2.0f * t);
+}
+__device__ __forceinline__ uint32_t blend_srgb8(uint32_t d, float r, float g, float b, float a_in, const float* __restrict__ lut) {
+    const float a = sat_f(a_in), ia = 1.0f - a;
+    const uint32_t o0 = srgb8(sat_f(r) * a + lut[d & 255u] * ia);
+    const uint32_t o1 = srgb8(sat_f(g) * a + lut[(d >> 8) & 255u] * ia);
+    const uint32_t o2 = srgb8(sat_f(b) * a + lut[(d >> 16) & 255u] * ia);
+    const float oa = a * 1.0f + ((float)(d >> 24) / 255.0f) * ia;
+    const uint32_t o3 = (uint32_t)(int)(sat_f(oa) * 255.0f + 0.5f);
+    return o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
+}
+
+__global__ __launch_bounds__(256) void k_overlay(OverlayParams p) {
+    __shared__ float s_lut[256];
+    __shared__ Prim2D s_prims[256];
+    __shared__ uint32_t s_wave_count[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
+    if (p.world > 1u && !owns_tile(tx, ty, p.rank, p.world)) return;
+    s_lut[tid] = p.srgb_lut[tid];
+    const int32_t tile_x0 = (int32_t)(tx * kTile), tile_y0 = (int32_t)(ty * kTile);
+    // sub-pixel bounds of the tile's pixel centres
+    const int32_t cx_lo = tile_x0 * kSub + kSub / 2, cx_hi = (tile_x0 + (int32_t)kTile - 1) * kSub + kSub / 2;
+    const int32_t cy_lo = tile_y0 * kSub + kSub / 2, cy_hi = (tile_y0 + (int32_t)kTile - 1) * kSub + kSub / 2;
+    uint32_t dst[4] = {0u, 0u, 0u, 0u};
+    __syncthreads();
+    if (p.fullscreen) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t local = k * 256u + tid;
+            const uint32_t i = (uint32_t)tile_x0 + (local & (kTile - 1)), j = (uint32_t)tile_y0 + local / kTile;
+            if (i >= p.sw || j >= p.sh) continue;
+            float depth = 1.0f;
+            if (p.depth_src) {
+                const float u = ((float)i + 0.5f) / (float)p.sw, v = ((float)j + 0.5f) / (float)p.sh;
+                const uint32_t x = min((uint32_t)floorf(u * (float)p.src_w), p.src_w - 1u), y = min((uint32_t)floorf(v * (float)p.src_h), p.src_h - 1u);
+                const size_t at = (size_t)((y / kTile) * p.src_tiles_x + x / kTile) * kTilePixels + ((y % kTile) * kTile + x % kTile);
+                depth = __uint_as_float((uint32_t)(p.depth_src[at] >> 32));
+            }
+            const float dd = (2.0f * 0.5f) / ((50.0f + 0.5f) - depth * (50.0f - 0.5f));
+            dst[k] = blend_srgb8(dst[k], dd, dd, dd, 1.0f, s_lut);
+        }
+    }
+    for (uint32_t base = 0; base < p.n_prims; base += 256u) {
+        // this batch's quads that are front-facing and reach the tile, kept in order
+        bool keep = false;
+        Prim2D q;
+        if (base + tid < p.n_prims) {
+            q = p.prims[base + tid];
+            const long long area = (long long)(q.xb - q.xa) * (long long)(q.yb - q.yt);
+            const int32_t x_lo = min(q.xa, q.xb), x_hi = max(q.xa, q.xb), y_lo = min(q.yt, q.yb), y_hi = max(q.yt, q.yb);
+            keep = area > 0 && x_lo <= cx_hi && x_hi > cx_lo && y_lo <= cy_hi && y_hi > cy_lo;
+        }
+        const unsigned long long km = __ballot(keep);
+        if (lane == 0) s_wave_count[wave] = (uint32_t)__popcll(km);
+        __syncthreads();
+        uint32_t off = 0, total = 0;
+        for (uint32_t w = 0; w < 4; ++w) { const uint32_t c = s_wave_count[w]; if (w < wave) off += c; total += c; }
+        if (keep) s_prims[off + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = q;
+        __syncthreads();
+        for (uint32_t n = 0; n < total; ++n) {
+            const Prim2D& r = s_prims[n];
+            const int32_t x_lo = min(r.xa, r.xb), x_hi = max(r.xa, r.xb), y_lo = min(r.yt, r.yb), y_hi = max(r.yt, r.yb);
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                const uint32_t local = k * 256u + tid;
+                const int32_t px = (tile_x0 + (int32_t)(local & (kTile - 1))) * kSub + kSub / 2;
+                const int32_t py = (tile_y0 + (int32_t)(local / kTile)) * kSub + kSub / 2;
+                if (px < x_lo || px >= x_hi || py < y_lo || py >= y_hi) continue;
+                if (r.kind == 0u) {
+                    dst[k] = blend_srgb8(dst[k], r.color[0], r.color[1], r.color[2], r.color[3], s_lut);
+                } else {
+                    const float u = (float)(px - r.xa) / (float)(r.xb - r.xa), v = (float)(py - r.yt) / (float)(r.yb - r.yt);
+                    const float cell = 1.0f / 128.0f;
+                    const float u0 = (0.0f / 128.0f) + (float)r.glyph * cell, u1 = (1.0f / 128.0f) + (float)r.glyph * cell;
+                    const float tu = u0 + (u1 - u0) * u;
+                    const f32x4 sd = texture_bilinear(p.font, 0u, tu, v);
+                    const float ratio = (r.font_size - 12.0f) / (24.0f - 12.0f);
+                    const float smoothing = fminf(fmaxf(0.25f + ratio * (0.15f - 0.25f), 0.1f), 0.9f);
+                    const float fill_dist = smoothstep_f(0.37f - smoothing, 0.37f + smoothing, sd.z);
+                    const float outline_dist = smoothstep_f(0.8f - smoothing, 0.8f + smoothing, sd.z);
+                    const float fill_alpha = 1.0f - fill_dist, alpha = 1.0f - outline_dist;
+                    const float col = 0.0f * (1.0f - fill_alpha) + 1.0f * fill_alpha;
+                    dst[k] = blend_srgb8(dst[k], col, col, col, alpha, s_lut);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // out: the 2D target, and the 2D target over the presented frame
+    uint32_t compact = 0;
+    if (p.world > 1u) compact = ((ty / kOwnerGroup / p.world) * kOwnerGroup + ty % kOwnerGroup) * p.tiles_x + tx;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t local = k * 256u + tid;
+        const uint32_t i = (uint32_t)tile_x0 + (local & (kTile - 1)), j = (uint32_t)tile_y0 + local / kTile;
+        if (i >= p.sw || j >= p.sh) continue;
+        const size_t at = (size_t)j * p.sw + i;
+        if (p.overlay_out) p.overlay_out[at] = dst[k];
+        if ((dst[k] >> 24) == 0u) continue;
+        uint32_t* f = p.frame ? p.frame + at : p.tiles + (size_t)compact * kTilePixels + local;
+        const uint32_t d = dst[k], old = *f;
+        const float a = (float)(d >> 24) / 255.0f, ia = 1.0f - a;
+        const uint32_t o0 = srgb8(s_lut[d & 255u] * a + s_lut[old & 255u] * ia);
+        const uint32_t o1 = srgb8(s_lut[(d >> 8) & 255u] * a + s_lut[(old >> 8) & 255u] * ia);
+        const uint32_t o2 = srgb8(s_lut[(d >> 16) & 255u] * a + s_lut[(old >> 16) & 255u] * ia);
+        *f = o0 | (o1 << 8) | (o2 << 16) | (old & 0xFF000000u);
+    }
+}
+
 __global__ void k_present(const float* __restrict__ hdr, uint32_t w, uint32_t h, uint32_t* __restrict__ frame,
                           uint32_t sw, uint32_t sh, uint32_t linear, uint32_t tone) {
     const uint32_t i = blockIdx.x * 64u + (threadIdx.x & 63u), j = blockIdx.y * 4u + (threadIdx.x >> 6);
@@ -1744,6 +1866,10 @@ void launch_present(const float* hdr, uint32_t w, uint32_t h, uint8_t* frame_rgb
                     bool linear, uint32_t tone, hipStream_t stream) {
     hipLaunchKernelGGL(k_present, dim3(div_up(sw, 64), div_up(sh, 4)), dim3(256), 0, stream, hdr, w, h,
                        reinterpret_cast<uint32_t*>(frame_rgba8), sw, sh, linear ? 1u : 0u, tone);
+}
+void launch_overlay(const OverlayParams& p, uint32_t n_tiles, hipStream_t stream) {
+    if (!n_tiles) return;
+    hipLaunchKernelGGL(k_overlay, dim3(n_tiles), dim3(256), 0, stream, p);
 }
 void launch_unpack(const uint64_t* packed, const FrameConst& fc, uint8_t* frame_rgba8, float* depth, hipStream_t stream) {
     size_t n = (size_t)fc.width * fc.height;

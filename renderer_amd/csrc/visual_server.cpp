@@ -68,6 +68,16 @@ VisualServer::VisualServer(uint32_t width, uint32_t height, int device) : device
     static const uint32_t quad_idx[6] = {0, 2, 1, 1, 2, 3};
     rnd_submesh_desc d{quad, 4, quad_idx, 6, RND_NONE};
     register_mesh(kQuadMeshId, 1, &d);
+    // font texture default (visual_server.rs:82) and the sRGB decode table of the 2D blends
+    static const uint8_t yellow[4] = {255, 255, 0, 255};
+    set_font_image(1, 1, yellow);
+    float lut[256];
+    for (int v = 0; v < 256; ++v) {
+        const double c = v / 255.0;
+        lut[v] = (float)(c <= 0.04045 ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4));
+    }
+    d_srgb_lut_.ensure(256);
+    HIP_CHECK(hipMemcpy(d_srgb_lut_.ptr, lut, sizeof lut, hipMemcpyHostToDevice));
 }
 
 VisualServer::~VisualServer() {
@@ -85,7 +95,7 @@ VisualServer::~VisualServer() {
     d_shadow_order_.release();
     for (auto& b : shadow_layers_) b.release();
     d_launch_order_.release(); d_vis_.release(); d_frame_.release(); d_tiles_.release(); d_packed_.release();
-    d_hdr_.release();
+    d_hdr_.release(); d_font_.release(); d_srgb_lut_.release(); d_overlay_.release(); d_present_.release();
     for (auto& kv : detile_lists_) kv.second.list.release();
     for (auto& s : staging_) {
         if (s.host) (void)hipHostFree(s.host);
@@ -341,6 +351,81 @@ void VisualServer::reset_scene() {
     for (auto& kv : textures_) kv.second.texels.release();
     textures_.clear();
     materials_.clear(); lights_.clear(); mesh_instances_.clear(); sprite_materials_.clear();
+    fullscreen_ = 0;        // RenderScene::fullscreen_texture (visual_server.rs:903)
+}
+
+// ---- 2D overlay state ----------------------------------------------------------------------------
+void VisualServer::set_uiboxes(uint32_t n, const rnd_uibox* boxes) {
+    if (n && !boxes) throw Error(RND_ERR_INVALID, "null boxes");
+    uiboxes_.assign(boxes, boxes + n);
+}
+
+void VisualServer::set_font_image(uint32_t w, uint32_t h, const uint8_t* rgba8) {
+    if (!w || !h || !rgba8 || w > 16384 || h > 16384) throw Error(RND_ERR_INVALID, "bad font image");
+    std::vector<float> texels((size_t)w * h * 4);
+    for (size_t k = 0; k < texels.size(); ++k) texels[k] = (float)(rgba8[k] / 255.0);      // create_color_texture_linear: Rgba8Unorm
+    use_device();
+    finish();
+    d_font_.ensure(texels.size());
+    HIP_CHECK(hipMemcpy(d_font_.ptr, texels.data(), texels.size() * sizeof(float), hipMemcpyHostToDevice));
+    font_w_ = w; font_h_ = h;
+}
+
+void VisualServer::reset_texts() { glyphs_.clear(); }
+
+void VisualServer::add_text(const uint8_t* text, uint32_t n, float x, float y, float font_size) {
+    if (n && !text) throw Error(RND_ERR_INVALID, "null text");
+    for (uint32_t i = 0; i < n; ++i) {      // visual_server.rs:556-570
+        Glyph g;
+        g.pos[0] = x + (float)i * font_size * 1.1667f * 0.5f; g.pos[1] = y + 0.0f;
+        g.scale[0] = font_size * 1.1667f * 0.5f; g.scale[1] = font_size;
+        g.glyph = std::min<uint32_t>(text[i], 127u);
+        glyphs_.push_back(g);
+    }
+}
+
+void VisualServer::set_depth_fullscreen_texture() { fullscreen_ = 1; }
+void VisualServer::set_shadow_map_fullscreen_texture(UniqueNodeId light) {
+    for (const RenderLight& l : lights_)
+        if (l.id == light) { fullscreen_ = 2; fullscreen_light_ = light; return; }
+    // "warning: no such light registered" and return (visual_server.rs:329-332)
+}
+void VisualServer::unset_fullscreen_texture() { fullscreen_ = 0; }
+
+// The instanced quads after their vertex stage (uibox.wgsl:30-42, text.wgsl:39-51): corner (cx, cy) in
+// {0,1}^2 at pos + c*size, y measured from the top of the surface, to clip space, through the viewport
+// transform and onto the sub-pixel grid (raster rule 2), each step rounded in f32 as the shader does.
+void VisualServer::build_prims(std::vector<Prim2D>& prims) const {
+    const float vw = (float)surface_w_, vh = (float)surface_h_, half_w = 0.5f * vw, half_h = 0.5f * vh;
+    auto snap = [](float s) { return (int32_t)std::fmin(std::fmax(std::nearbyint(s * (float)kSub), -1.0e9f), 1.0e9f); };
+    auto quad = [&](const float pos[2], const float size[2], Prim2D& q) {
+        auto sx = [&](float cx) { const float tp = cx * size[0] + pos[0]; const float clip = (tp / vw) * 2.0f - 1.0f; return snap((clip + 1.0f) * half_w); };
+        auto sy = [&](float cy) { const float tp = cy * size[1] + ((vh - pos[1]) - size[1]); const float clip = (tp / vh) * 2.0f - 1.0f; return snap((1.0f - clip) * half_h); };
+        q.xa = sx(0.0f); q.xb = sx(1.0f); q.yt = sy(1.0f); q.yb = sy(0.0f);
+    };
+    prims.reserve(uiboxes_.size() + glyphs_.size());
+    for (const rnd_uibox& b : uiboxes_) {
+        Prim2D q{};
+        quad(b.position, b.size, q);
+        for (int k = 0; k < 3; ++k) q.color[k] = std::pow(b.color[k], 2.2f);     // uibox.wgsl:27-28
+        q.color[3] = b.color[3];
+        q.kind = 0;
+        prims.push_back(q);
+    }
+    for (const Glyph& g : glyphs_) {
+        Prim2D q{};
+        quad(g.pos, g.scale, q);
+        q.kind = 1; q.glyph = g.glyph; q.font_size = g.scale[1];
+        prims.push_back(q);
+    }
+}
+
+void VisualServer::read_overlay_rgba8(uint8_t* dst) {
+    finish(); need_frame();
+    const size_t bytes = (size_t)surface_w_ * surface_h_ * 4;
+    if (!overlay_drawn_) { std::memset(dst, 0, bytes); return; }
+    use_device();
+    HIP_CHECK(hipMemcpy(dst, d_overlay_.ptr, bytes, hipMemcpyDeviceToHost));
 }
 
 // ---- frame -------------------------------------------------------------------------------------
@@ -542,7 +627,12 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     for (uint32_t smp = 1; smp < msaa_; ++smp) sample_shift(smp, consts[n_passes + smp].sub_dx, consts[n_passes + smp].sub_dy);
     constexpr size_t kConstSlot = (sizeof(FrameConst) + 255) / 256 * 256;
     const size_t off_fc = align_up(off_ss + n_sets * sizeof(ShadowSet), 256);
-    const size_t total = align_up(off_fc + consts.size() * kConstSlot + 256, 256);
+    // the 2D pass's quads, when anything 2D is set
+    const bool overlay = fullscreen_ != 0 || !uiboxes_.empty() || !glyphs_.empty();
+    std::vector<Prim2D> prims;
+    if (overlay) build_prims(prims);
+    const size_t off_pr = align_up(off_fc + consts.size() * kConstSlot, 256);
+    const size_t total = align_up(off_pr + prims.size() * sizeof(Prim2D) + 256, 256);
     lap(0);
     Staging& st = staging_[staging_next_];
     staging_next_ = (staging_next_ + 1) % 3;
@@ -565,6 +655,9 @@ void VisualServer::enqueue_frame(bool want_hdr) {
         std::memcpy(h + off_ss, sets.data(), n_sets * sizeof(ShadowSet));
     }
     for (size_t k = 0; k < consts.size(); ++k) std::memcpy(h + off_fc + k * kConstSlot, &consts[k], sizeof(FrameConst));
+    if (!prims.empty()) std::memcpy(h + off_pr, prims.data(), prims.size() * sizeof(Prim2D));
+    if (overlay) d_overlay_.ensure((size_t)surface_w_ * surface_h_);
+    overlay_drawn_ = overlay;
     // one device block with the same layout; the frame's first clear kernel copies it over from the
     // pinned block (no hipMemcpyAsync: each one costs the host ~8 us and the GPU a blit kernel)
     d_tables_.ensure(total + total / 2);
@@ -670,6 +763,29 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     launch_shade(fb, fc, stream_);
     if (scaled())   // show_texture.wgsl over the surface (visual_server.rs:629-633: filtered sampler above factor 1)
         launch_present(d_hdr_.ptr, width_, height_, d_present_.ptr, surface_w_, surface_h_, render_size_factor_ > 1.0f, tone_mapping_, stream_);
+    if (overlay) {
+        // Pipeline2d::render + the second draw of Backend::render, over the frame just presented
+        OverlayParams op{};
+        op.prims = reinterpret_cast<const Prim2D*>(tb + off_pr); op.n_prims = (uint32_t)prims.size();
+        op.srgb_lut = d_srgb_lut_.ptr;
+        op.font = TextureDesc{d_font_.ptr, font_w_, font_h_, 1u, 0u};
+        op.fullscreen = (uint32_t)fullscreen_;
+        if (fullscreen_ == 1) { op.depth_src = d_vis_.ptr; op.src_w = width_; op.src_h = height_; op.src_tiles_x = tiles_x_; }
+        else if (fullscreen_ == 2) {
+            for (uint32_t k = 0; k < n_sets; ++k)
+                if (lights_[shadowed[k]].id == fullscreen_light_) {
+                    op.depth_src = shadow_layers_[k].ptr;       // layer 0 (build_fullscreen_texture_array_bind_group(.., 0))
+                    op.src_w = op.src_h = kShadowSize; op.src_tiles_x = kShadowSize / kTile;
+                }
+        }
+        op.sw = surface_w_; op.sh = surface_h_; op.tiles_x = (surface_w_ + kTile - 1) / kTile;
+        op.rank = rank_; op.world = world_;
+        op.frame = world_ > 1 ? nullptr : reinterpret_cast<uint32_t*>(scaled() ? d_present_.ptr : d_frame_.ptr);
+        op.tiles = world_ > 1 ? reinterpret_cast<uint32_t*>(fb.tiles_rgba8) : nullptr;
+        op.overlay_out = d_overlay_.ptr;
+        if (world_ > 1) HIP_CHECK(hipMemsetAsync(d_overlay_.ptr, 0, (size_t)surface_w_ * surface_h_ * 4, stream_));
+        launch_overlay(op, op.tiles_x * ((surface_h_ + kTile - 1) / kTile), stream_);
+    }
     mark(6);
     };
     // The kernel sequence only depends on buffer addresses, capacities and the scene's shape (the
@@ -679,7 +795,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     // the replay costs the host as much as the launches (25.7 vs 30.1 us of 61 us per frame) and the
     // frame rate does not move, so the plain launches stay the default.
     bool launched = false;
-    if (use_graphs_ && !timed) {
+    if (use_graphs_ && !timed && !overlay) {
         std::vector<uint8_t> key;
         auto add = [&](const void* p, size_t n) { const uint8_t* b = static_cast<const uint8_t*>(p); key.insert(key.end(), b, b + n); };
         add(&fb, sizeof fb); add(&cap_, sizeof cap_);

@@ -107,6 +107,16 @@ public:
     void set_sprite(UniqueNodeId id, const Mat4& transform, uint32_t texture_id, const float color[4]);
     void reset_scene();
 
+    // 2D overlay — visual_server.rs:192-204, :313-348, :476-479, :552-577 (Pipeline2d)
+    void set_uiboxes(uint32_t n, const rnd_uibox* boxes);
+    void set_font_image(uint32_t w, uint32_t h, const uint8_t* rgba8);
+    void reset_texts();
+    void add_text(const uint8_t* text, uint32_t n, float x, float y, float font_size);
+    void set_depth_fullscreen_texture();
+    void set_shadow_map_fullscreen_texture(UniqueNodeId light);
+    void unset_fullscreen_texture();
+    void read_overlay_rgba8(uint8_t* dst);
+
     // frame — visual_server.rs:224-311
     void render();
     void finish();
@@ -194,6 +204,19 @@ private:
     std::vector<RenderMeshInstance> mesh_instances_;
     std::unordered_map<UniqueNodeId, uint32_t> sprite_materials_;
     uint32_t next_sprite_material_ = 0x80000000u;
+
+    // 2D state: UiBoxInstance list, GlyphInstance list of every text, font atlas, debug view
+    struct Glyph { float pos[2], scale[2]; uint32_t glyph; };       // pipeline2d/glyph_instance.rs:5-9
+    std::vector<rnd_uibox> uiboxes_;
+    std::vector<Glyph> glyphs_;
+    DeviceBuffer<float> d_font_;          // RGBA f32 (Rgba8Unorm), one level
+    uint32_t font_w_ = 0, font_h_ = 0;
+    DeviceBuffer<float> d_srgb_lut_;
+    DeviceBuffer<uint32_t> d_overlay_;    // the 2D target of the last frame that drew one
+    int fullscreen_ = 0;                  // 0 none, 1 depth, 2 shadow map of fullscreen_light_
+    UniqueNodeId fullscreen_light_ = 0;
+    bool overlay_drawn_ = false;
+    void build_prims(std::vector<Prim2D>& prims) const;
 
     // SceneUniform — visual_server.rs:887-894
     Mat4 projection_, view_, camera_transform_;

@@ -353,3 +353,116 @@ def test_msaa4():
         vs.set_msaa(1)
         vs.render()
     assert_parity(pair[0], pair[1], min_covered=320 * 180 // 2)
+
+
+def overlay_content(vs, rng_seed, w, h, font=True):
+    """Random UI boxes (some translucent, some culled, some off-screen), an SDF font atlas and texts."""
+    from renderer_amd.types import Image
+    rng = np.random.default_rng(rng_seed)
+    boxes = []
+    for _ in range(40):
+        pos = (float(rng.uniform(-20, w)), float(rng.uniform(-20, h)))
+        size = (float(rng.uniform(-5, 90)), float(rng.uniform(1, 60)))
+        boxes.append((pos, size, tuple(float(x) for x in rng.uniform(0, 1, 4))))
+    boxes.append(((0.0, 0.0), (float(w), 8.0), (0.2, 0.2, 0.2, 1.0)))
+    vs.set_uiboxes(boxes)
+    if font:
+        atlas = rng.integers(0, 256, size=(16, 128 * 8, 4), dtype=np.uint8)
+        vs.set_font_image(vs.asset_server.add(Image(128 * 8, 16, atlas)))
+    vs.reset_texts()
+    vs.add_text(0, "Hello text! \x7f\xff", (20.0, 20.0), 24.0)
+    vs.add_text(1, "fps: 2236.4 | triangles 10000000", (4.5, float(h) - 30.25), 16.0)
+    vs.add_text(2, "tiny", (float(w) - 20.0, 50.0), 9.0)
+
+
+def assert_overlay_parity(gpu, cpu):
+    ov_g, ov_c = gpu.read_overlay_rgba8().astype(int), cpu.read_overlay_rgba8().astype(int)
+    # coverage of the 2D pass is integer work: where anything was drawn must agree exactly
+    assert ((ov_g[..., 3] != 0) == (ov_c[..., 3] != 0)).all()
+    assert ov_c[..., 3].any()
+    # colours: f32 blends with an 8-bit store after each draw; powf / division differ in the last bit
+    # between the device and host libraries, which can move a store across a rounding boundary, and a
+    # later translucent draw carries that on
+    d = np.abs(ov_g - ov_c).max(axis=-1)
+    assert d.max() <= 2 and (d > 1).mean() <= 1e-3, (d.max(), (d > 1).mean())
+    img_g, img_c = gpu.read_color_rgba8().astype(int), cpu.read_color_rgba8().astype(int)
+    d = np.abs(img_g - img_c).max(axis=-1)
+    assert d.max() <= 2 and (d > 1).mean() <= 1e-3, (d.max(), (d > 1).mean())
+
+
+def test_overlay_boxes_text_over_a_scene():
+    """N4: Pipeline2d's pass (UI boxes, SDF text) composited over the 3D frame."""
+    s = soup_scene(41, 320, 200, n_meshes=3, n_tri=60, lights=2)
+    s.lights = [l for l in s.lights if l[2].kind_id() == 1]
+    gpu, cpu = render_pair(s)
+    for vs in (gpu, cpu):
+        overlay_content(vs, 5, s.width, s.height)
+        vs.render()
+    assert_overlay_parity(gpu, cpu)
+    # the 3D planes are untouched by the 2D pass
+    assert (gpu.read_depth().view(np.uint32) == cpu.read_depth().view(np.uint32)).all()
+    # default font (one yellow texel) and no boxes
+    for vs in (VisualServer(96, 64, device=0), oracle_server(96, 64)):
+        vs.add_text(0, "ab", (2.0, 3.0), 12.0)
+        vs.render()
+        ov = vs.read_overlay_rgba8()
+        assert (ov[3:15, 2:16] == 255).all() and not ov[15:].any()
+    # everything unset again: the overlay is empty and the frame is the plain 3D image
+    for vs in (gpu, cpu):
+        vs.set_uiboxes([])
+        vs.reset_texts()
+        vs.render()
+        assert not vs.read_overlay_rgba8().any()
+    assert_parity(gpu, cpu, min_covered=3000)
+
+
+def test_overlay_fullscreen_debug_views():
+    """set_depth_fullscreen_texture / set_shadow_map_fullscreen_texture under boxes and text; also with
+    a scaled 3D target (the depth texture then has the 3D resolution, the overlay the surface's)."""
+    s = shadow_scene()
+    gpu, cpu = render_pair(s)
+    for vs in (gpu, cpu):
+        overlay_content(vs, 6, s.width, s.height, font=False)
+        vs.set_depth_fullscreen_texture()
+        vs.render()
+    assert_overlay_parity(gpu, cpu)
+    ov = cpu.read_overlay_rgba8()
+    assert (ov[..., 3] == 255).all()
+    for vs in (gpu, cpu):
+        vs.set_shadow_map_fullscreen_texture(9)
+        vs.render()
+    assert_overlay_parity(gpu, cpu)
+    for vs in (gpu, cpu):
+        vs.set_render_size_factor(0.5)
+        vs.set_depth_fullscreen_texture()
+        vs.render()
+    assert gpu.render_resolution() == (160, 100)
+    assert_overlay_parity(gpu, cpu)
+
+
+def test_overlay_on_a_tile_partition():
+    """Each rank composites the 2D pass into the tiles it owns; the union is the single-context frame."""
+    s = soup_scene(43, 320, 288, n_meshes=3, n_tri=60, lights=2)
+    s.lights = [l for l in s.lights if l[2].kind_id() == 1]
+    whole = VisualServer(s.width, s.height, device=0)
+    s.populate(whole)
+    overlay_content(whole, 7, s.width, s.height)
+    whole.set_depth_fullscreen_texture()
+    whole.render()
+    want, want_ov = whole.read_color_rgba8(), whole.read_overlay_rgba8()
+    got, got_ov = np.zeros_like(want), np.zeros_like(want_ov)
+    world = 3
+    for rank in range(world):
+        vs = VisualServer(s.width, s.height, device=0)
+        vs.set_tile_partition(rank, world)
+        s.populate(vs)
+        overlay_content(vs, 7, s.width, s.height)
+        vs.set_depth_fullscreen_texture()
+        vs.render()
+        img = vs.read_color_rgba8()
+        ov = vs.read_overlay_rgba8()
+        ty = (np.arange(s.height) // 32 // 4) % world == rank
+        got[ty] = img[ty]
+        got_ov[ty] = ov[ty]
+        assert not ov[~ty].any()
+    assert (got == want).all() and (got_ov == want_ov).all()
