@@ -27,6 +27,15 @@ pub struct rnd_vertex {
     pub uv: [f32; 2],
 }
 
+/// reference: UiBoxInstance, src/renderer/pipeline2d/uibox_instance.rs:5-11
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rnd_uibox {
+    pub position: [f32; 2],
+    pub size: [f32; 2],
+    pub color: [f32; 4],
+}
+
 #[repr(C)]
 pub struct rnd_submesh_desc {
     pub vertices: *const rnd_vertex,
@@ -103,6 +112,14 @@ extern "C" {
     pub fn rnd_frame_stats_get(ctx: *mut rnd_ctx, out: *mut rnd_frame_stats) -> c_int;
 
     pub fn rnd_set_tile_partition(ctx: *mut rnd_ctx, rank: u32, world: u32) -> c_int;
+    pub fn rnd_set_uiboxes(ctx: *mut rnd_ctx, n: u32, boxes: *const rnd_uibox) -> c_int;
+    pub fn rnd_set_font_image(ctx: *mut rnd_ctx, width: u32, height: u32, rgba8: *const u8) -> c_int;
+    pub fn rnd_reset_texts(ctx: *mut rnd_ctx) -> c_int;
+    pub fn rnd_add_text(ctx: *mut rnd_ctx, text: *const u8, n_bytes: u32, x: f32, y: f32, font_size: f32) -> c_int;
+    pub fn rnd_set_depth_fullscreen_texture(ctx: *mut rnd_ctx) -> c_int;
+    pub fn rnd_set_shadow_map_fullscreen_texture(ctx: *mut rnd_ctx, light_id: u64) -> c_int;
+    pub fn rnd_unset_fullscreen_texture(ctx: *mut rnd_ctx) -> c_int;
+    pub fn rnd_read_overlay_rgba8(ctx: *mut rnd_ctx, dst: *mut u8) -> c_int;
     pub fn rnd_tile_info(ctx: *const rnd_ctx, tile_px: *mut u32, n_owned_tiles: *mut u32, n_tiles_total: *mut u32) -> c_int;
     pub fn rnd_tiles_device_ptr(ctx: *mut rnd_ctx, dev_ptr: *mut *mut c_void, n_bytes: *mut u64) -> c_int;
     pub fn rnd_set_tiles_output(ctx: *mut rnd_ctx, dev_ptr: *mut c_void, n_bytes: u64) -> c_int;
