@@ -126,6 +126,19 @@ struct SetupRecord {
 static_assert(sizeof(SetupRecord) == 48, "SetupRecord is 3 x 16 bytes");
 
 // Device-side counters of one frame.
+// A vertex after K1's viewport transform and snap (raster rule 4), with its clip-space verdicts, so that
+// K2a's per-triangle work starts from integers: each vertex is shared by about six triangles.
+struct SnapVert {
+    int32_t x, y;                 // snapped position, 1/256 px (before the MSAA sample shift)
+    float z;                      // z / w
+    uint32_t code;                // kOut* bits
+};
+static_assert(sizeof(SnapVert) == 16, "SnapVert layout");
+constexpr uint32_t kOutPlanes = 0x3Fu;        // bit p: outside view-volume plane p (x+w, w-x, y+w, w-y, z, w-z < 0)
+constexpr uint32_t kOutNeedsClip = 0x100u;    // outside near/far or the guard band: the triangle goes to the clipper
+constexpr uint32_t kOutNonFinite = 0x200u;    // a non-finite clip coordinate: the triangle is dropped
+constexpr uint32_t kOutBehind = 0x400u;       // w <= 0
+
 // ---- 2D overlay (pipeline2d.rs) --------------------------------------------------------------
 // One instanced quad of the 2D pass after its vertex stage: a UI box (uibox.wgsl) or a glyph (text.wgsl).
 struct Prim2D {

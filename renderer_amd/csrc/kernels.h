@@ -27,6 +27,7 @@ struct FrameBuffers {
     uint32_t* vblock_needed;        // per kVertexBlock block of the frame's vertex slots: used by a surviving unit
     // geometry stage
     float4* clip;                   // n_verts clip positions
+    SnapVert* snap;                 // n_verts snapped positions + clip verdicts (K1 -> K2a)
     SetupRecord* records;
     uint2* tilewords;               // per record: .x = tx0 | ty0<<8 | (w-1)<<16 | (h-1)<<24, .y = position in its bin (single-tile records)
     uint32_t* clip_queue;           // triangle ids that need the clipper

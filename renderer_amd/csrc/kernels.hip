@@ -231,9 +231,30 @@ __global__ __launch_bounds__(256) void k_cull(FrameBuffers fb) {
     }
 }
 
+struct Snapped { int32_t x, y; float z; };
+__device__ __forceinline__ bool snap_vertex(float cx, float cy, float cz, float cw, float half_w,
+                                            float half_h, Snapped& s, int32_t sub_dx, int32_t sub_dy);
+
+// The per-vertex half of triangle setup: snap (rule 4) and the vertex's verdicts against the view
+// volume and the guard band (rules 2, 3).  For finite a, b the rounded sum a + b has the sign of the
+// exact sum (and is zero only if that is), so x < -w  <=>  x + w < 0 and x > w  <=>  w - x < 0.
+// (kGuardBand is a power of two: kGuardBand * w is exact.)
+__device__ __forceinline__ SnapVert snap_and_classify(const float4& c, float half_w, float half_h) {
+    Snapped s;
+    const bool front = snap_vertex(c.x, c.y, c.z, c.w, half_w, half_h, s, 0, 0);
+    const bool finite = isfinite(c.x) && isfinite(c.y) && isfinite(c.z) && isfinite(c.w);
+    const float g = kGuardBand * c.w, zf = c.w - c.z;
+    uint32_t code = (c.x + c.w < 0.0f ? 1u : 0u) | (c.w - c.x < 0.0f ? 2u : 0u) | (c.y + c.w < 0.0f ? 4u : 0u) |
+                    (c.w - c.y < 0.0f ? 8u : 0u) | (c.z < 0.0f ? 16u : 0u) | (zf < 0.0f ? 32u : 0u);
+    const bool clip = c.z < 0.0f || zf < 0.0f || c.x + g < 0.0f || g - c.x < 0.0f || c.y + g < 0.0f || g - c.y < 0.0f;
+    code |= (clip ? kOutNeedsClip : 0u) | (finite ? 0u : kOutNonFinite) | (front ? 0u : kOutBehind);
+    return SnapVert{s.x, s.y, s.z, code};
+}
+
 __global__ __launch_bounds__(256) void k_transform(const DrawItem* __restrict__ items,
                                                    const uint32_t* __restrict__ vert_bases, const FrameConst* __restrict__ fcp,
-                                                   float4* __restrict__ clip, const uint32_t* __restrict__ vblock_needed,
+                                                   float4* __restrict__ clip, SnapVert* __restrict__ snap,
+                                                   const uint32_t* __restrict__ vblock_needed,
                                                    const FrameCounters* __restrict__ counters) {
     FrameConstRef fc = frame_const_ref(fcp);
     static_assert(kVertexBlock == 256, "one workgroup per vertex block");
@@ -251,6 +272,8 @@ __global__ __launch_bounds__(256) void k_transform(const DrawItem* __restrict__ 
             float x = ((gptr_f32)d.px)[v], y = ((gptr_f32)d.py)[v], z = ((gptr_f32)d.pz)[v];
             float4 c = clip_position(d, fc, x, y, z);
             clip[gid] = c;
+            const SnapVert sv = snap_and_classify(c, 0.5f * (float)fc.width, 0.5f * (float)fc.height);
+            *reinterpret_cast<uint4*>(snap + gid) = make_uint4((uint32_t)sv.x, (uint32_t)sv.y, __float_as_uint(sv.z), sv.code);
         }
     }
 }
@@ -258,8 +281,6 @@ __global__ __launch_bounds__(256) void k_transform(const DrawItem* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // K2: triangle setup
 // ------------------------------------------------------------------------------------------
-struct Snapped { int32_t x, y; float z; };
-
 // (sub_dx, sub_dy): whole sub-pixel steps added after the snap.  With MSAA, sample k of a pixel at
 // offset (ox, oy) from the pixel's corner is the pixel centre of the geometry moved by
 // (1/2 - ox, 1/2 - oy); the offsets of the 4x pattern are multiples of 1/16 px, exact on the grid.
@@ -507,40 +528,19 @@ __device__ __forceinline__ uint32_t count_wave(bool emit, const TileRect& t, Fra
     return single ? base + my_rank : kNoBinPos;
 }
 
-// Reject / cull / snap / record of one triangle whose vertices need no clipping; sets need_clip
-// (and emits nothing) when it must go through the clipper.
-__device__ __forceinline__ void setup_triangle(const float4& c0, const float4& c1, const float4& c2, uint32_t gid,
-                                               FrameConstRef fc, float half_w, float half_h, SetupRecord& rec,
-                                               TileRect& tr, bool& emit, bool& need_clip) {
-    bool finite = isfinite(c0.x) && isfinite(c0.y) && isfinite(c0.z) && isfinite(c0.w) &&
-                  isfinite(c1.x) && isfinite(c1.y) && isfinite(c1.z) && isfinite(c1.w) &&
-                  isfinite(c2.x) && isfinite(c2.y) && isfinite(c2.z) && isfinite(c2.w);
-    // Trivial reject against the view volume and the "needs the clipper" test.  For finite a, b the
-    // rounded sum a + b has the sign of the exact sum (and is zero only if that is), so
-    // x < -w  <=>  x + w < 0 and x > w  <=>  w - x < 0; "all three outside" is then a max3 below zero
-    // and "any outside" a min3 below zero.  (kGuardBand is a power of two: kGuardBand * w is exact.)
-    const float xl0 = c0.x + c0.w, xl1 = c1.x + c1.w, xl2 = c2.x + c2.w;      // >= 0 inside the left plane
-    const float xr0 = c0.w - c0.x, xr1 = c1.w - c1.x, xr2 = c2.w - c2.x;
-    const float yl0 = c0.y + c0.w, yl1 = c1.y + c1.w, yl2 = c2.y + c2.w;
-    const float yr0 = c0.w - c0.y, yr1 = c1.w - c1.y, yr2 = c2.w - c2.y;
-    const float zf0 = c0.w - c0.z, zf1 = c1.w - c1.z, zf2 = c2.w - c2.z;      // >= 0 in front of the far plane
-    // The six per-plane results are folded with min before the one comparison: no short-circuit chain.
-    const float out_m = fminf(fminf(fminf(fmaxf(fmaxf(xl0, xl1), xl2), fmaxf(fmaxf(xr0, xr1), xr2)),
-                                    fminf(fmaxf(fmaxf(yl0, yl1), yl2), fmaxf(fmaxf(yr0, yr1), yr2))),
-                              fminf(fmaxf(fmaxf(c0.z, c1.z), c2.z), fmaxf(fmaxf(zf0, zf1), zf2)));
-    const float g0 = kGuardBand * c0.w, g1 = kGuardBand * c1.w, g2 = kGuardBand * c2.w;
-    const float clip_m = fminf(fminf(fminf(fminf(fminf(c0.z, c1.z), c2.z), fminf(fminf(zf0, zf1), zf2)),
-                                     fminf(fminf(fminf(c0.x + g0, c1.x + g1), c2.x + g2), fminf(fminf(g0 - c0.x, g1 - c1.x), g2 - c2.x))),
-                               fminf(fminf(fminf(c0.y + g0, c1.y + g1), c2.y + g2), fminf(fminf(g0 - c0.y, g1 - c1.y), g2 - c2.y)));
-    const bool go = finite && !(out_m < 0.0f);
-    need_clip = go && clip_m < 0.0f;
+// Reject / cull / record of one triangle from its three pre-snapped vertices (K1 did the per-vertex
+// work: snap_and_classify); sets need_clip (and emits nothing) when it must go through the clipper.
+__device__ __forceinline__ void setup_triangle(const SnapVert& v0, const SnapVert& v1, const SnapVert& v2, uint32_t gid,
+                                               FrameConstRef fc, SetupRecord& rec, TileRect& tr, bool& emit, bool& need_clip) {
+    const uint32_t any = v0.code | v1.code | v2.code, all = v0.code & v1.code & v2.code;
+    // dropped: a non-finite coordinate, or all three vertices outside one plane of the view volume
+    const bool go = !(any & kOutNonFinite) && !(all & kOutPlanes);
+    need_clip = go && (any & kOutNeedsClip) != 0u;
     if (go && !need_clip) {
-        Snapped s0, s1, s2;
-        const bool ok0 = snap_vertex(c0.x, c0.y, c0.z, c0.w, half_w, half_h, s0, fc.sub_dx, fc.sub_dy);
-        const bool ok1 = snap_vertex(c1.x, c1.y, c1.z, c1.w, half_w, half_h, s1, fc.sub_dx, fc.sub_dy);
-        const bool ok2 = snap_vertex(c2.x, c2.y, c2.z, c2.w, half_w, half_h, s2, fc.sub_dx, fc.sub_dy);
+        const Snapped s0{v0.x + fc.sub_dx, v0.y + fc.sub_dy, v0.z}, s1{v1.x + fc.sub_dx, v1.y + fc.sub_dy, v1.z},
+                      s2{v2.x + fc.sub_dx, v2.y + fc.sub_dy, v2.z};
         const bool rec_ok = make_record(s0, s1, s2, gid, fc, rec, tr);
-        emit = ok0 && ok1 && ok2 && rec_ok && any_owned(tr, fc);
+        emit = !(any & kOutBehind) && rec_ok && any_owned(tr, fc);
     }
 }
 
@@ -645,7 +645,6 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
     gptr_u32 indices = (gptr_u32)d->indices;
     const bool tables_ok = guard(vb + nv <= fc.n_verts, fb.counters, kGuardSetup);
     const uint32_t chunk_base = blockIdx.x * kSetupChunk;
-    const float half_w = 0.5f * (float)fc.width, half_h = 0.5f * (float)fc.height;
     const uint32_t n_tiles = fc.tiles_x * fc.tiles_y;
     const GlobalSink direct_sink{reinterpret_cast<unsigned long long*>(fb.vis), fc.tiles_x, fc.rank, fc.world};
     uint32_t valid = 0;
@@ -659,10 +658,13 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
             gptr_u32 ix = indices + 3ull * (first_t + local);
             const uint32_t i0 = ix[0], i1 = ix[1], i2 = ix[2];
             if (guard(i0 < nv && i1 < nv && i2 < nv, fb.counters, kGuardSetup)) {
-                const float4 c0 = fb.clip[vb + i0];
-                const float4 c1 = fb.clip[vb + i1];
-                const float4 c2 = fb.clip[vb + i2];
-                setup_triangle(c0, c1, c2, gid, fc, half_w, half_h, rec, tr, emit, need_clip);
+                const uint4 q0 = *reinterpret_cast<const uint4*>(fb.snap + vb + i0);
+                const uint4 q1 = *reinterpret_cast<const uint4*>(fb.snap + vb + i1);
+                const uint4 q2 = *reinterpret_cast<const uint4*>(fb.snap + vb + i2);
+                const SnapVert v0{(int32_t)q0.x, (int32_t)q0.y, __uint_as_float(q0.z), q0.w};
+                const SnapVert v1{(int32_t)q1.x, (int32_t)q1.y, __uint_as_float(q1.z), q1.w};
+                const SnapVert v2{(int32_t)q2.x, (int32_t)q2.y, __uint_as_float(q2.z), q2.w};
+                setup_triangle(v0, v1, v2, gid, fc, rec, tr, emit, need_clip);
                 if (alpha_item) rec.flags |= 2u;
             }
         }
@@ -1797,7 +1799,7 @@ void launch_cull(const FrameBuffers& fb, const FrameConst& fc, hipStream_t strea
 
 void launch_transform(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream) {
     if (!fc.n_verts) return;
-    hipLaunchKernelGGL(k_transform, dim3(div_up(fc.n_verts, 256)), dim3(256), 0, stream, fb.items, fb.vert_bases, fb.frame_const, fb.clip,
+    hipLaunchKernelGGL(k_transform, dim3(div_up(fc.n_verts, 256)), dim3(256), 0, stream, fb.items, fb.vert_bases, fb.frame_const, fb.clip, fb.snap,
                        fb.vblock_needed, fb.counters);
 }
 void launch_setup(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {

@@ -87,7 +87,7 @@ VisualServer::~VisualServer() {
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (auto& kv : meshes_)
         for (auto& s : kv.second.submeshes) { s.vertex_buffer.release(); s.positions.release(); s.index_buffer.release(); s.chunks.release(); }
-    d_tables_.release(); d_clip_.release();
+    d_tables_.release(); d_clip_.release(); d_snap_.release();
     d_records_.release(); d_tilewords_.release(); d_clip_queue_.release(); d_chunk_count_.release(); d_vblock_needed_.release(); d_active_units_.release(); d_tile_count_.release();
     d_tile_offset_.release(); d_tile_cursor_.release(); d_entries_.release(); d_counters_.release();
     for (auto& kv : textures_) kv.second.texels.release();
@@ -595,6 +595,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     const uint64_t want_entries = std::max<uint64_t>(4ull * cap_.records + 16ull * n_tiles, 1u << 20);
     if (cap_.entries < want_entries) cap_.entries = (uint32_t)std::min<uint64_t>(want_entries, 0xFFFFFFF0ull);
     d_clip_.ensure(std::max<size_t>(fc.n_verts, 1));
+    d_snap_.ensure(std::max<size_t>(fc.n_verts, 1));
     d_records_.ensure(cap_.records); d_tilewords_.ensure(2 * (size_t)cap_.records);
     d_clip_queue_.ensure(cap_.clip_queue);
     d_chunk_count_.ensure(std::max<size_t>(2 * (size_t)fc.n_units, 2));
@@ -673,7 +674,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     fb.alpha_test = frame_alpha_test_ ? 1u : 0u;
     fb.has_textures = frame_textured_ ? 1u : 0u;
     fb.shadow_sets = n_sets ? reinterpret_cast<const ShadowSet*>(tb + off_ss) : nullptr;      // null selects the shading kernel without the lookup
-    fb.clip = d_clip_.ptr; fb.records = d_records_.ptr; fb.tilewords = reinterpret_cast<uint2*>(d_tilewords_.ptr); fb.clip_queue = d_clip_queue_.ptr;
+    fb.clip = d_clip_.ptr; fb.snap = d_snap_.ptr; fb.records = d_records_.ptr; fb.tilewords = reinterpret_cast<uint2*>(d_tilewords_.ptr); fb.clip_queue = d_clip_queue_.ptr;
     fb.chunk_count = d_chunk_count_.ptr;
     fb.unit_bases = reinterpret_cast<const uint32_t*>(tb + off_ub); fb.active_units = reinterpret_cast<uint2*>(d_active_units_.ptr); fb.vblock_needed = d_vblock_needed_.ptr;
     fb.tile_count = d_tile_count_.ptr; fb.tile_offset = d_tile_offset_.ptr; fb.tile_cursor = d_tile_cursor_.ptr;

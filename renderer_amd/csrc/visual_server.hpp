@@ -226,6 +226,7 @@ private:
     // device state
     DeviceBuffer<uint8_t> d_tables_;                // per-frame tables (items, bases, lights, shadow items and sets), one upload
     DeviceBuffer<float4> d_clip_;
+    DeviceBuffer<SnapVert> d_snap_;
     DeviceBuffer<SetupRecord> d_records_;
     DeviceBuffer<uint32_t> d_tilewords_, d_clip_queue_, d_chunk_count_, d_vblock_needed_, d_active_units_, d_tile_count_, d_tile_offset_, d_tile_cursor_, d_entries_;
     DeviceBuffer<FrameCounters> d_counters_;        // [0] main pass, then one per shadow pass
