@@ -1318,6 +1318,7 @@ __device__ __forceinline__ void add_light(const GpuLight& L, PixelInputs& p, con
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct PixelPair {
     f32x2 fx, fy, fz, Nx, Ny, Nz, Vx, Vy, Vz, br, bg, bb, cr, cg, cb;
+    f32x2 ar, ag, ab;       // sum over the lights of colour * intensity * (diffuse + specular)
     bool lit0, lit1;
 };
 __device__ __forceinline__ f32x2 splat2(float v) { return (f32x2){v, v}; }
@@ -1361,10 +1362,12 @@ __device__ __forceinline__ void add_light_pair(const GpuLight& L, PixelPair& p, 
     f32x2 inv_h = rsq2(hx * hx + hy * hy + hz * hz);
     f32x2 sp = max0((p.Nx * hx + p.Ny * hy + p.Nz * hz) * inv_h);
     f32x2 s2 = sp * sp, s4 = s2 * s2, s8 = s4 * s4;
+    // the lights' sum is kept apart from the base colour and multiplied in once after the loop
+    // (base * sum(c_l * w_l) for sum(base * c_l * w_l): three packed multiplies less per light)
     f32x2 w = (diff + s8) * inten;
-    p.cr += (p.br * splat2(L.color[0])) * w;
-    p.cg += (p.bg * splat2(L.color[1])) * w;
-    p.cb += (p.bb * splat2(L.color[2])) * w;
+    p.ar += splat2(L.color[0]) * w;
+    p.ag += splat2(L.color[1]) * w;
+    p.ab += splat2(L.color[2]) * w;
 }
 #endif
 
@@ -1482,6 +1485,7 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(
         RND_PAIR(Vz); RND_PAIR(br); RND_PAIR(bg); RND_PAIR(bb); RND_PAIR(cr); RND_PAIR(cg); RND_PAIR(cb);
 #undef RND_PAIR
         pp.lit0 = px[0].lit; pp.lit1 = px[1].lit;
+        pp.ar = pp.ag = pp.ab = splat2(0.0f);
     }
 #endif
     if (lo[0] <= hi[0]) {
@@ -1521,6 +1525,7 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(
     }
 #if RND_FAST_SHADE
     if constexpr (PPT == 2) {
+        pp.cr += pp.br * pp.ar; pp.cg += pp.bg * pp.ag; pp.cb += pp.bb * pp.ab;
         px[0].cr = pp.cr.x; px[0].cg = pp.cg.x; px[0].cb = pp.cb.x;
         px[1].cr = pp.cr.y; px[1].cg = pp.cg.y; px[1].cb = pp.cb.y;
     }
