@@ -9,13 +9,14 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
+from renderer_amd import scenes  # noqa: E402
 
 
 def main():
     many = min(16, os.cpu_count() or 1)
     for name in ("c1", "c2", "c3"):
         builder, desc = bench.WORKLOADS[name]
-        scene = getattr(bench.scenes, builder)()
+        scene = getattr(scenes, builder)()
         for threads in (1, many):
             r = bench.cpu_baseline(scene, desc, threads)
             r["workload"] = name
