@@ -96,8 +96,9 @@ def algorithmic_bytes(stats, n_visible_tris):
     nv, nt = stats["n_vertices"], stats["n_triangles"]
     nrec, nbin, p = stats["n_setup"], stats["n_bin_entries"], stats["n_pixels"]
     return {
-        "transform": 12 * nv + 16 * nv + 8 * p,               # SoA positions in, clip xyzw out; + the visibility clear timed with it
-        # indices, each clip position once, one 8-byte visibility word per pixel (direct small-triangle
+        # SoA positions in, clip xyzw and the snapped vertex (x, y, z/w, outcodes) out; + the visibility clear timed with it
+        "transform": 12 * nv + 16 * nv + 16 * nv + 8 * p,
+        # indices, each snapped vertex once, one 8-byte visibility word per pixel (direct small-triangle
         # path), and for the triangles that go through the bins a 48-byte record + (tile word, bin pos)
         "setup": 12 * nt + 16 * nv + 8 * p + 56 * min(nbin, nrec),
         "bin": 12 * min(nbin, nrec) + 4 * nbin,               # (tile word, bin pos) + tile offset in, bin entries out
