@@ -466,3 +466,38 @@ def test_overlay_on_a_tile_partition():
         got_ov[ty] = ov[ty]
         assert not ov[~ty].any()
     assert (got == want).all() and (got_ov == want_ov).all()
+
+
+def test_degenerate_and_nonfinite_geometry():
+    """Edge cases of rules 2-5: zero-area and repeated-vertex triangles, NaN / inf positions, a vertex on
+    the camera plane (w = 0) and behind it, triangles far outside the guard band, sub-pixel slivers, a
+    submesh without triangles - mixed into a soup so that every path (direct raster, bins, clipper) sees
+    them.  The verdicts now come from K1's per-vertex outcodes; the oracle decides per triangle."""
+    w, h = 160, 120
+    s = soup_scene(77, w, h, n_meshes=2, n_tri=40, lights=2)
+    s.lights = [l for l in s.lights if l[2].kind_id() == 1]
+    nan, inf = float("nan"), float("inf")
+    tris = [
+        [(-0.5, -0.5, 2.0), (0.5, -0.5, 2.0), (0.0, 0.5, 2.0)],          # plain, facing the camera or not
+        [(0.5, -0.5, 2.1), (-0.5, -0.5, 2.1), (0.0, 0.5, 2.1)],          # the other winding
+        [(-1.0, 0.0, 3.0), (0.0, 0.0, 3.0), (1.0, 0.0, 3.0)],            # collinear
+        [(0.3, 0.3, 2.5), (0.3, 0.3, 2.5), (0.6, 0.1, 2.5)],             # repeated vertex
+        [(nan, 0.0, 2.0), (0.5, 0.5, 2.0), (0.5, -0.5, 2.0)],
+        [(0.2, inf, 2.0), (0.6, 0.5, 2.0), (0.6, -0.5, 2.0)],
+        [(0.2, 0.1, -inf), (0.6, 0.5, 2.0), (0.6, -0.5, 2.0)],
+        [(-0.8, -0.6, 1.0), (-0.2, -0.6, 1.0), (-0.5, 0.4, 1.0)],        # cam_z = -1: this one sits at view z = 2
+        [(-0.8, 0.6, -1.0), (-0.2, 0.6, 4.0), (-0.5, -0.4, 4.0)],        # one vertex exactly on the camera plane
+        [(0.8, 0.6, -3.0), (0.2, 0.6, 4.0), (0.5, -0.4, 4.0)],           # one vertex behind the camera
+        [(-400.0, -300.0, 5.0), (400.0, -300.0, 5.0), (0.0, 500.0, 5.0)],      # far outside the guard band (16x the view), covers the frame
+        [(3.0e5, 0.0, 6.0), (3.0e5 + 1.0, 0.0, 6.0), (3.0e5, 1.0, 6.0)],       # entirely outside the view volume
+        [(0.1001, 0.1, 2.2), (0.1002, 0.1, 2.2), (0.10015, 0.1002, 2.2)],      # far below a pixel
+        [(1.0e-30, 0.0, 1.0e-30), (0.0, 1.0e-30, 1.0e-30), (0.0, 0.0, 1.0e-30)],
+    ]
+    pos = np.asarray(tris, dtype=np.float32).reshape(-1, 3)
+    idx = np.arange(len(pos), dtype=np.uint32)
+    idx = np.concatenate([idx, idx[::-1]])                               # every triangle with both windings
+    s.meshes.append(Mesh([Submesh(make_vertices(pos), idx), Submesh(make_vertices(pos[:3]), np.zeros(0, np.uint32))]))
+    s.instances.append((90, identity(), len(s.meshes) - 1))
+    gpu, cpu = render_pair(s)
+    assert_parity(gpu, cpu, min_covered=int(0.9 * w * h))
+    assert np.isfinite(gpu.read_color_hdr()).all()
