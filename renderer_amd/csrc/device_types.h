@@ -8,6 +8,7 @@ namespace rnd {
 
 constexpr uint32_t kTile = 32;                 // square screen tile edge in pixels
 constexpr uint32_t kTilePixels = kTile * kTile;
+constexpr uint32_t kDirectPixels = 32;        // K2a rasterizes a triangle itself when its bbox holds at most this many pixel centres (RND_DIRECT_PIXELS, <= 64)
 constexpr uint32_t kOwnerGroup = 4;            // sort-first ownership: full-width stripes of this many tile rows, dealt round-robin
 constexpr int kSubpixelBits = 8;
 constexpr int kSub = 1 << kSubpixelBits;       // 256 sub-pixel steps per pixel

@@ -592,8 +592,8 @@ template <bool kAlpha, class Sink>
 __device__ __forceinline__ void direct_pixel(const DirectTri& d, uint32_t k, const Sink& sink, const FrameBuffers& fb,
                                              FrameConstRef fc) {
     const uint32_t w = d.shape & 255u;
-    // k / w for k < 16, w <= 16: (k + 0.5) / w is at least 1/32 away from an integer, far beyond the
-    // 1 ulp of the approximate reciprocal
+    // k / w for k < 64, w <= 64: (k + 0.5) / w is at least 1/128 away from an integer, far beyond the
+    // 1 ulp of the approximate reciprocal (absolute error below 1e-5 at these magnitudes)
     const uint32_t dj = (uint32_t)(((float)k + 0.5f) * d.inv_w);
     const uint32_t di = k - dj * w;
     const int32_t w0 = d.r0 + __mul24((int32_t)dj, d.sx0) - __mul24((int32_t)di, d.sy0);
@@ -610,7 +610,7 @@ __device__ __forceinline__ void direct_pixel(const DirectTri& d, uint32_t k, con
     }
 }
 
-// A triangle whose bbox holds at most kSmallPixels pixel centres (the bulk at C2..C5 density) is
+// A triangle whose bbox holds at most fb.direct_pixels pixel centres (kDirectPixels; the bulk at C2..C5 density) is
 // rasterized right here by its lane, straight into the visibility buffer (GlobalSink); only the
 // larger ones become records and go through the bins to the per-tile raster kernel.
 // Slots of the record stream are deterministic: workgroup b owns slots [b*kSetupChunk,
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
         valid += (uint32_t)__popcll(__ballot(emit));
         // small triangles: rasterize now, no record
         const bool direct = emit && (rec.flags & 1u) &&
-                            (uint32_t)(tr.i1 - tr.i0 + 1) * (uint32_t)(tr.j1 - tr.j0 + 1) <= kSmallPixels;
+                            (uint32_t)(tr.i1 - tr.i0 + 1) * (uint32_t)(tr.j1 - tr.j0 + 1) <= fb.direct_pixels;
         const unsigned long long dm = __ballot(direct);
         if (dm) {
             if (direct) {

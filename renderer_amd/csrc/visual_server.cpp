@@ -674,6 +674,10 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     fb.alpha_test = frame_alpha_test_ ? 1u : 0u;
     fb.has_textures = frame_textured_ ? 1u : 0u;
     fb.shadow_sets = n_sets ? reinterpret_cast<const ShadowSet*>(tb + off_ss) : nullptr;      // null selects the shading kernel without the lookup
+    // measured: 16 -> 32 takes C4 (bboxes of ~20 pixel centres) from 230 to 285 frames/s by keeping it out of the
+    // record/bin/raster path; C3 and C5 do not move; 64 gains nothing more and costs C1
+    static const uint32_t direct_pixels = [] { const char* e = std::getenv("RND_DIRECT_PIXELS"); int v = e ? std::atoi(e) : (int)kDirectPixels; return (uint32_t)std::min(std::max(v, 0), 64); }();
+    fb.direct_pixels = direct_pixels;
     fb.clip = d_clip_.ptr; fb.snap = d_snap_.ptr; fb.records = d_records_.ptr; fb.tilewords = reinterpret_cast<uint2*>(d_tilewords_.ptr); fb.clip_queue = d_clip_queue_.ptr;
     fb.chunk_count = d_chunk_count_.ptr;
     fb.unit_bases = reinterpret_cast<const uint32_t*>(tb + off_ub); fb.active_units = reinterpret_cast<uint2*>(d_active_units_.ptr); fb.vblock_needed = d_vblock_needed_.ptr;
