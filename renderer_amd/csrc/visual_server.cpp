@@ -55,7 +55,14 @@ VisualServer::VisualServer(uint32_t width, uint32_t height, int device) : device
         for (auto& e : es.ev) HIP_CHECK(hipEventCreate(&e));
     for (auto& s : staging_) HIP_CHECK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_counters_), sizeof(FrameCounters), hipHostMallocDefault));
-    d_counters_.ensure(1);
+    d_counters_[0].ensure(1); d_counters_[1].ensure(1);
+    HIP_CHECK(hipStreamCreateWithFlags(&geo_stream_, hipStreamNonBlocking));     // (a higher or lower stream priority changes nothing measurable)
+    for (int k = 0; k < 2; ++k) {
+        HIP_CHECK(hipEventCreateWithFlags(&geo_done_[k], hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&shade_done_[k], hipEventDisableTiming));
+    }
+    if (const char* e = std::getenv("RND_OVERLAP")) overlap_ = std::atoi(e) != 0;
+    if (use_graphs_) overlap_ = false;      // a captured frame is one stream's sequence
     // SceneUniform defaults — visual_server.rs:63-68
     projection_ = perspective_lh(1.3f, 1.667f, 0.05f, 100.0f);
     view_ = Mat4::identity();
@@ -82,19 +89,21 @@ VisualServer::VisualServer(uint32_t width, uint32_t height, int device) : device
 
 VisualServer::~VisualServer() {
     (void)hipSetDevice(device_);
+    if (geo_stream_) (void)hipStreamSynchronize(geo_stream_);
     if (stream_) (void)hipStreamSynchronize(stream_);
     for (CachedGraph& g : graphs_)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (auto& kv : meshes_)
         for (auto& s : kv.second.submeshes) { s.vertex_buffer.release(); s.positions.release(); s.index_buffer.release(); s.chunks.release(); }
-    d_tables_.release(); d_clip_.release(); d_snap_.release();
+    for (int k = 0; k < 2; ++k) { d_tables_[k].release(); d_clip_[k].release(); d_vis_[k].release(); d_counters_[k].release(); }
+    d_snap_.release();
     d_records_.release(); d_tilewords_.release(); d_clip_queue_.release(); d_chunk_count_.release(); d_vblock_needed_.release(); d_active_units_.release(); d_tile_count_.release();
-    d_tile_offset_.release(); d_tile_cursor_.release(); d_entries_.release(); d_counters_.release();
+    d_tile_offset_.release(); d_tile_cursor_.release(); d_entries_.release();
     for (auto& kv : textures_) kv.second.texels.release();
     d_textures_.release();
     d_shadow_order_.release();
     for (auto& b : shadow_layers_) b.release();
-    d_launch_order_.release(); d_vis_.release(); d_frame_.release(); d_tiles_.release(); d_packed_.release();
+    d_launch_order_.release(); d_frame_.release(); d_tiles_.release(); d_packed_.release();
     d_hdr_.release(); d_font_.release(); d_srgb_lut_.release(); d_overlay_.release(); d_present_.release();
     for (auto& kv : detile_lists_) kv.second.list.release();
     for (auto& s : staging_) {
@@ -105,6 +114,11 @@ VisualServer::~VisualServer() {
     for (auto& es : event_sets_)
         for (auto& e : es.ev) if (e) (void)hipEventDestroy(e);
     if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
+    if (geo_stream_) (void)hipStreamDestroy(geo_stream_);
+    for (int k = 0; k < 2; ++k) {
+        if (geo_done_[k]) (void)hipEventDestroy(geo_done_[k]);
+        if (shade_done_[k]) (void)hipEventDestroy(shade_done_[k]);
+    }
 }
 
 void VisualServer::use_device() const { HIP_CHECK(hipSetDevice(device_)); }
@@ -168,7 +182,7 @@ void VisualServer::rebuild_tiles() {
     if (n_owned_) HIP_CHECK(hipMemcpy(d_launch_order_.ptr, order.data(), n_owned_ * sizeof(TileRef), hipMemcpyHostToDevice));
     const size_t n_tiles = (size_t)tiles_x_ * tiles_y_;
     d_tile_count_.ensure(2 * n_tiles); d_tile_offset_.ensure(n_tiles); d_tile_cursor_.ensure(n_tiles);
-    d_vis_.ensure(n_tiles * kTilePixels * msaa_);
+    d_vis_[0].ensure(n_tiles * kTilePixels * msaa_); d_vis_[1].ensure(n_tiles * kTilePixels * msaa_);
     d_frame_.ensure((size_t)width_ * height_ * 4);
     if (world_ > 1) d_tiles_.ensure(std::max<size_t>((size_t)n_owned_ * kTilePixels * 4, 4));
 }
@@ -543,6 +557,9 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     auto lap = [&](int k) { if (prof) { auto t = now(); acc[k] += std::chrono::duration<double, std::micro>(t - t_prev).count(); t_prev = t; } };
     use_device();
     if (scaled()) want_hdr = true;      // the present pass samples the HDR target
+    const uint32_t p = parity_ ^ 1u;    // this frame's copy of the buffers that geometry writes and shading reads
+    parity_ = p;
+    hipStream_t const gs = overlap_ ? geo_stream_ : stream_;      // the geometry phase's stream
     std::vector<DrawItem> items;
     std::vector<uint32_t> vert_bases, tri_bases, unit_bases;
     std::vector<GpuLight> lights;
@@ -576,7 +593,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
         d_tile_count_.ensure(2 * need); d_tile_offset_.ensure(need); d_tile_cursor_.ensure(need);
     }
     n_counter_sets_ = 1 + n_passes + (msaa_ - 1);
-    d_counters_.ensure(n_counter_sets_);
+    d_counters_[p].ensure(n_counter_sets_);
     if (h_counter_sets_ < n_counter_sets_) {
         if (frame_pending_) HIP_CHECK(hipStreamSynchronize(stream_));
         if (h_counters_) HIP_CHECK(hipHostFree(h_counters_));
@@ -594,7 +611,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     if (cap_.clip_queue < std::max<uint32_t>(fc.n_tris / 8, 65536)) cap_.clip_queue = std::max<uint32_t>(fc.n_tris / 8, 65536);
     const uint64_t want_entries = std::max<uint64_t>(4ull * cap_.records + 16ull * n_tiles, 1u << 20);
     if (cap_.entries < want_entries) cap_.entries = (uint32_t)std::min<uint64_t>(want_entries, 0xFFFFFFF0ull);
-    d_clip_.ensure(std::max<size_t>(fc.n_verts, 1));
+    d_clip_[p].ensure(std::max<size_t>(fc.n_verts, 1));
     d_snap_.ensure(std::max<size_t>(fc.n_verts, 1));
     d_records_.ensure(cap_.records); d_tilewords_.ensure(2 * (size_t)cap_.records);
     d_clip_queue_.ensure(cap_.clip_queue);
@@ -661,8 +678,8 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     overlay_drawn_ = overlay;
     // one device block with the same layout; the frame's first clear kernel copies it over from the
     // pinned block (no hipMemcpyAsync: each one costs the host ~8 us and the GPU a blit kernel)
-    d_tables_.ensure(total + total / 2);
-    uint8_t* const tb = d_tables_.ptr;
+    d_tables_[p].ensure(total + total / 2);
+    uint8_t* const tb = d_tables_[p].ptr;
 
     lap(2);
     FrameBuffers fb{};
@@ -678,13 +695,13 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     // record/bin/raster path; C3 and C5 do not move; 64 gains nothing more and costs C1
     static const uint32_t direct_pixels = [] { const char* e = std::getenv("RND_DIRECT_PIXELS"); int v = e ? std::atoi(e) : (int)kDirectPixels; return (uint32_t)std::min(std::max(v, 0), 64); }();
     fb.direct_pixels = direct_pixels;
-    fb.clip = d_clip_.ptr; fb.snap = d_snap_.ptr; fb.records = d_records_.ptr; fb.tilewords = reinterpret_cast<uint2*>(d_tilewords_.ptr); fb.clip_queue = d_clip_queue_.ptr;
+    fb.clip = d_clip_[p].ptr; fb.snap = d_snap_.ptr; fb.records = d_records_.ptr; fb.tilewords = reinterpret_cast<uint2*>(d_tilewords_.ptr); fb.clip_queue = d_clip_queue_.ptr;
     fb.chunk_count = d_chunk_count_.ptr;
     fb.unit_bases = reinterpret_cast<const uint32_t*>(tb + off_ub); fb.active_units = reinterpret_cast<uint2*>(d_active_units_.ptr); fb.vblock_needed = d_vblock_needed_.ptr;
     fb.tile_count = d_tile_count_.ptr; fb.tile_offset = d_tile_offset_.ptr; fb.tile_cursor = d_tile_cursor_.ptr;
-    fb.entries = d_entries_.ptr; fb.counters = d_counters_.ptr;
+    fb.entries = d_entries_.ptr; fb.counters = d_counters_[p].ptr;
     fb.launch_order = d_launch_order_.ptr; fb.n_owned = n_owned_;
-    fb.vis = d_vis_.ptr;
+    fb.vis = d_vis_[p].ptr;
     fb.vis_stride = (uint64_t)tiles_x_ * tiles_y_ * kTilePixels;
     fb.frame_rgba8 = (world_ > 1 || scaled()) ? nullptr : d_frame_.ptr;
     fb.tiles_rgba8 = world_ > 1 ? (ext_tiles_ ? ext_tiles_ : d_tiles_.ptr) : nullptr;
@@ -705,66 +722,78 @@ void VisualServer::enqueue_frame(bool want_hdr) {
         ev_ = es.ev;
         timed_set = &es;
     }
-    auto mark = [&](int k) { if (ev_) HIP_CHECK(hipEventRecord(ev_[k], stream_)); };
+    auto mark = [&](int k, hipStream_t on) { if (ev_) HIP_CHECK(hipEventRecord(ev_[k], on)); };
     auto emit = [&]() {
     bool tables_pending = true;
     auto clear = [&](const FrameBuffers& b, const FrameConst& c) {
-        if (tables_pending) launch_clear(b, c, stream_, h, tb, total);
-        else launch_clear(b, c, stream_);
+        if (tables_pending) launch_clear(b, c, gs, h, tb, total);
+        else launch_clear(b, c, gs);
         tables_pending = false;
     };
     // shadow cascades: depth-only passes of the same pipeline (cull, transform, setup, bins, raster)
     // into kShadowSize^2 visibility buffers, one per (directional light, cascade)
-    mark(7);
+    if (overlap_) {
+        // this parity's buffers were last read by the shading of the frame before the previous one; the
+        // shadow layers exist once (the previous frame's shading reads them), and a frame with timing
+        // events runs alone so that its kernel durations are its own
+        HIP_CHECK(hipStreamWaitEvent(gs, shade_done_[p], 0));
+        if (n_sets || last_had_sets_ || timed || serialize_next_) HIP_CHECK(hipStreamWaitEvent(gs, shade_done_[p ^ 1u], 0));
+    }
+    mark(7, gs);
     for (uint32_t k = 0; k < n_sets; ++k)
         for (uint32_t c = 0; c < kShadowCascades; ++c) {
             FrameBuffers sfb = fb;
             sfb.items = reinterpret_cast<const DrawItem*>(tb + off_si); sfb.lights = nullptr; sfb.shadow_sets = nullptr; sfb.alpha_test = 0;
-            sfb.counters = d_counters_.ptr + 1 + k * kShadowCascades + c;
+            sfb.counters = d_counters_[p].ptr + 1 + k * kShadowCascades + c;
             sfb.launch_order = d_shadow_order_.ptr; sfb.n_owned = kShadowTiles;
             sfb.vis = shadow_layers_[k].ptr + (size_t)c * kShadowTiles * kTilePixels;
             sfb.frame_rgba8 = nullptr; sfb.tiles_rgba8 = nullptr; sfb.packed = nullptr; sfb.hdr = nullptr;
             const FrameConst& sfc = consts[1 + k * kShadowCascades + c];
             sfb.frame_const = const_slot(1 + k * kShadowCascades + c);
             clear(sfb, sfc);
-            launch_cull(sfb, sfc, stream_);
-            launch_transform(sfb, sfc, stream_);
-            launch_setup(sfb, sfc, cap_, stream_);
-            launch_clip(sfb, sfc, cap_, stream_);
-            launch_scan(sfb, sfc, cap_, stream_);
-            launch_bin(sfb, sfc, cap_, stream_);
-            launch_raster(sfb, sfc, cap_, stream_);
+            launch_cull(sfb, sfc, gs);
+            launch_transform(sfb, sfc, gs);
+            launch_setup(sfb, sfc, cap_, gs);
+            launch_clip(sfb, sfc, cap_, gs);
+            launch_scan(sfb, sfc, cap_, gs);
+            launch_bin(sfb, sfc, cap_, gs);
+            launch_raster(sfb, sfc, cap_, gs);
         }
-    mark(0);
+    mark(0, gs);
     clear(fb, fc);                      // visibility words, tile counts, vertex-block flags, frame counters
-    launch_cull(fb, fc, stream_);       // work units that can reach the view volume and this context's stripes
-    launch_transform(fb, fc, stream_);
-    mark(1);
-    launch_setup(fb, fc, cap_, stream_);
-    launch_clip(fb, fc, cap_, stream_);
-    mark(2);
-    launch_scan(fb, fc, cap_, stream_);
-    mark(3);
-    launch_bin(fb, fc, cap_, stream_);
-    mark(4);
-    launch_raster(fb, fc, cap_, stream_);
+    launch_cull(fb, fc, gs);       // work units that can reach the view volume and this context's stripes
+    launch_transform(fb, fc, gs);
+    mark(1, gs);
+    launch_setup(fb, fc, cap_, gs);
+    launch_clip(fb, fc, cap_, gs);
+    mark(2, gs);
+    launch_scan(fb, fc, cap_, gs);
+    mark(3, gs);
+    launch_bin(fb, fc, cap_, gs);
+    mark(4, gs);
+    launch_raster(fb, fc, cap_, gs);
     // MSAA: the other samples' visibility planes, one more geometry pass each with the snapped
     // vertices moved so that the sample sits on the pixel centre (clip positions are shared)
     for (uint32_t smp = 1; smp < msaa_; ++smp) {
         FrameBuffers mfb = fb;
-        mfb.vis = d_vis_.ptr + (size_t)smp * fb.vis_stride;
-        mfb.counters = d_counters_.ptr + 1 + n_passes + (smp - 1);
+        mfb.vis = d_vis_[p].ptr + (size_t)smp * fb.vis_stride;
+        mfb.counters = d_counters_[p].ptr + 1 + n_passes + (smp - 1);
         const FrameConst& mfc = consts[n_passes + smp];
         mfb.frame_const = const_slot(n_passes + smp);
         clear(mfb, mfc);
-        launch_cull(mfb, mfc, stream_);
-        launch_setup(mfb, mfc, cap_, stream_);
-        launch_clip(mfb, mfc, cap_, stream_);
-        launch_scan(mfb, mfc, cap_, stream_);
-        launch_bin(mfb, mfc, cap_, stream_);
-        launch_raster(mfb, mfc, cap_, stream_);
+        launch_cull(mfb, mfc, gs);
+        launch_setup(mfb, mfc, cap_, gs);
+        launch_clip(mfb, mfc, cap_, gs);
+        launch_scan(mfb, mfc, cap_, gs);
+        launch_bin(mfb, mfc, cap_, gs);
+        launch_raster(mfb, mfc, cap_, gs);
     }
-    mark(5);
+    mark(5, gs);
+    if (overlap_) {
+        HIP_CHECK(hipEventRecord(geo_done_[p], gs));
+        HIP_CHECK(hipStreamWaitEvent(stream_, geo_done_[p], 0));
+    }
+    mark(8, stream_);       // shading starts here on its own stream (the hand-over from the geometry stream takes a few us)
     launch_shade(fb, fc, stream_);
     if (scaled())   // show_texture.wgsl over the surface (visual_server.rs:629-633: filtered sampler above factor 1)
         launch_present(d_hdr_.ptr, width_, height_, d_present_.ptr, surface_w_, surface_h_, render_size_factor_ > 1.0f, tone_mapping_, stream_);
@@ -775,7 +804,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
         op.srgb_lut = d_srgb_lut_.ptr;
         op.font = TextureDesc{d_font_.ptr, font_w_, font_h_, 1u, 0u};
         op.fullscreen = (uint32_t)fullscreen_;
-        if (fullscreen_ == 1) { op.depth_src = d_vis_.ptr; op.src_w = width_; op.src_h = height_; op.src_tiles_x = tiles_x_; }
+        if (fullscreen_ == 1) { op.depth_src = d_vis_[p].ptr; op.src_w = width_; op.src_h = height_; op.src_tiles_x = tiles_x_; }
         else if (fullscreen_ == 2) {
             for (uint32_t k = 0; k < n_sets; ++k)
                 if (lights_[shadowed[k]].id == fullscreen_light_) {
@@ -791,7 +820,8 @@ void VisualServer::enqueue_frame(bool want_hdr) {
         if (world_ > 1) HIP_CHECK(hipMemsetAsync(d_overlay_.ptr, 0, (size_t)surface_w_ * surface_h_ * 4, stream_));
         launch_overlay(op, op.tiles_x * ((surface_h_ + kTile - 1) / kTile), stream_);
     }
-    mark(6);
+    mark(6, stream_);
+    if (overlap_) HIP_CHECK(hipEventRecord(shade_done_[p], stream_));
     };
     // The kernel sequence only depends on buffer addresses, capacities and the scene's shape (the
     // frame's constants and tables are read from device memory), so frames without timing events can
@@ -809,7 +839,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
             add(dims, sizeof dims);
         }
         for (uint32_t k = 0; k < n_sets; ++k) { const void* p = shadow_layers_[k].ptr; add(&p, sizeof p); }
-        const void* ptrs[8] = {d_counters_.ptr, d_vis_.ptr, d_hdr_.ptr, d_present_.ptr, d_shadow_order_.ptr, tb, h, reinterpret_cast<const void*>(total)};
+        const void* ptrs[8] = {d_counters_[p].ptr, d_vis_[p].ptr, d_hdr_.ptr, d_present_.ptr, d_shadow_order_.ptr, tb, h, reinterpret_cast<const void*>(total)};
         add(ptrs, sizeof ptrs);
         const uint64_t misc[10] = {off_si, off_fc, n_sets, msaa_, surface_w_, surface_h_, width_, height_, tone_mapping_, render_size_factor_ > 1.0f ? 1u : 0u};
         add(misc, sizeof misc);
@@ -845,9 +875,11 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     lap(3);
     if (timed_set) timed_set->pending = true;
     // the pinned block is free again once this frame's first kernel has read it; recorded after the
-    // whole sequence so that it also holds for a graph replay (three blocks rotate)
-    HIP_CHECK(hipEventRecord(st.done, stream_));
+    // whole geometry sequence so that it also holds for a graph replay (three blocks rotate)
+    HIP_CHECK(hipEventRecord(st.done, gs));
     st.in_flight = true;
+    serialize_next_ = timed;
+    last_had_sets_ = n_sets > 0;
     // the frame's counters come back in finish(): only a frame somebody waits for needs them
     HIP_CHECK(hipGetLastError());
     lap(4);
@@ -870,7 +902,7 @@ void VisualServer::finish() {
     use_device();
     uint32_t grew = 0;
     for (int attempt = 0; attempt < 8; ++attempt) {
-        HIP_CHECK(hipMemcpyAsync(h_counters_, d_counters_.ptr, n_counter_sets_ * sizeof(FrameCounters), hipMemcpyDeviceToHost, stream_));
+        HIP_CHECK(hipMemcpyAsync(h_counters_, d_counters_[parity_].ptr, n_counter_sets_ * sizeof(FrameCounters), hipMemcpyDeviceToHost, stream_));
         HIP_CHECK(hipStreamSynchronize(stream_));
         frame_pending_ = false;
         FrameCounters c = h_counters_[0];
@@ -913,6 +945,7 @@ void VisualServer::harvest(EventSet& es) {
     HIP_CHECK(hipEventSynchronize(es.ev[6]));
     float ms[6] = {};
     for (int k = 0; k < 6; ++k) HIP_CHECK(hipEventElapsedTime(&ms[k], es.ev[k], es.ev[k + 1]));
+    HIP_CHECK(hipEventElapsedTime(&ms[5], es.ev[8], es.ev[6]));
     timings_ = rnd_timings{};
     timings_.transform_ms = ms[0]; timings_.setup_ms = ms[1]; timings_.scan_ms = ms[2]; timings_.bin_ms = ms[3];
     timings_.raster_ms = ms[4]; timings_.shade_ms = ms[5];
@@ -988,7 +1021,7 @@ void VisualServer::read_planes(float* depth, uint32_t* ids, uint8_t* coverage) {
         if (depth) { d_depth.ensure(n); HIP_CHECK(hipMemsetAsync(d_depth.ptr, 0, n * 4, stream_)); }
         if (ids) { d_ids.ensure(n); HIP_CHECK(hipMemsetAsync(d_ids.ptr, 0xFF, n * 4, stream_)); }
         if (coverage) { d_cov.ensure(n); HIP_CHECK(hipMemsetAsync(d_cov.ptr, 0, n, stream_)); }
-        launch_extract(d_vis_.ptr, d_launch_order_.ptr, n_owned_, fc_, d_depth.ptr, d_ids.ptr, d_cov.ptr, stream_);
+        launch_extract(d_vis_[parity_].ptr, d_launch_order_.ptr, n_owned_, fc_, d_depth.ptr, d_ids.ptr, d_cov.ptr, stream_);
         if (depth) HIP_CHECK(hipMemcpyAsync(depth, d_depth.ptr, n * 4, hipMemcpyDeviceToHost, stream_));
         if (ids) HIP_CHECK(hipMemcpyAsync(ids, d_ids.ptr, n * 4, hipMemcpyDeviceToHost, stream_));
         if (coverage) HIP_CHECK(hipMemcpyAsync(coverage, d_cov.ptr, n, hipMemcpyDeviceToHost, stream_));

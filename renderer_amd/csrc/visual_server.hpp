@@ -172,14 +172,14 @@ private:
     hipStream_t stream_ = nullptr;
     bool own_stream_ = true;
     // ring of per-frame event sets, so kernel timings can be harvested without a per-frame sync
-    static constexpr int kEventSets = 16, kEventsPerSet = 8;      // [7] = before the shadow passes
+    static constexpr int kEventSets = 16, kEventsPerSet = 9;      // [7] = before the shadow passes, [8] = before shading
     struct EventSet {
         hipEvent_t ev[kEventsPerSet] = {};
         bool pending = false;
     };
     EventSet event_sets_[kEventSets];
     uint32_t event_next_ = 0;
-    static constexpr uint64_t kTimingStride = 4;
+    static constexpr uint64_t kTimingStride = 16;     // a timed frame runs un-overlapped (two serialization points): keep them rare
     // instantiated HIP graphs of the frame's kernel sequence, keyed by the launches' by-value arguments
     static constexpr int kGraphSlots = 4;
     struct CachedGraph { std::vector<uint8_t> key; hipGraphExec_t exec = nullptr; };
@@ -224,18 +224,27 @@ private:
     float ambient_light_[4] = {0.3f, 0.5f, 0.9f, 0.04f};
 
     // device state
-    DeviceBuffer<uint8_t> d_tables_;                // per-frame tables (items, bases, lights, shadow items and sets), one upload
-    DeviceBuffer<float4> d_clip_;
+    // Consecutive frames overlap: the geometry phase of frame N+1 (clear .. raster, on geo_stream_) runs
+    // beside the shading of frame N (on stream_).  What shading reads from the geometry phase exists twice
+    // (index = frame parity): per-frame tables, clip positions, visibility buffer, counters.
+    hipStream_t geo_stream_ = nullptr;
+    hipEvent_t geo_done_[2] = {}, shade_done_[2] = {};
+    uint32_t parity_ = 0;              // buffers of the last enqueued frame
+    bool overlap_ = true;              // RND_OVERLAP=0: everything on stream_
+    bool serialize_next_ = false;      // the previous frame recorded timing events: keep this one's geometry off its shading
+    bool last_had_sets_ = false;       // the previous frame's shading reads the shadow layers
+    DeviceBuffer<uint8_t> d_tables_[2];             // per-frame tables (items, bases, lights, shadow items and sets), one upload
+    DeviceBuffer<float4> d_clip_[2];
     DeviceBuffer<SnapVert> d_snap_;
     DeviceBuffer<SetupRecord> d_records_;
     DeviceBuffer<uint32_t> d_tilewords_, d_clip_queue_, d_chunk_count_, d_vblock_needed_, d_active_units_, d_tile_count_, d_tile_offset_, d_tile_cursor_, d_entries_;
-    DeviceBuffer<FrameCounters> d_counters_;        // [0] main pass, then one per shadow pass
+    DeviceBuffer<FrameCounters> d_counters_[2];     // [0] main pass, then one per shadow pass
     uint32_t n_counter_sets_ = 1, h_counter_sets_ = 0;
     // shadow cascades of the directional lights
     DeviceBuffer<TileRef> d_shadow_order_;
     std::vector<DeviceBuffer<uint64_t>> shadow_layers_;   // per shadowed light: kShadowCascades visibility buffers
     DeviceBuffer<TileRef> d_launch_order_;
-    DeviceBuffer<uint64_t> d_vis_;
+    DeviceBuffer<uint64_t> d_vis_[2];
     DeviceBuffer<uint8_t> d_frame_, d_tiles_;
     DeviceBuffer<uint64_t> d_packed_;
     DeviceBuffer<float> d_hdr_;

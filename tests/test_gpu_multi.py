@@ -101,3 +101,40 @@ def test_sort_last_packed_min_composite():
     assert diff.max() <= 1
     depth = (comp.cpu().numpy().view(np.uint64) >> np.uint64(32)).astype(np.uint32).view(np.float32).reshape(s.height, s.width)
     assert (depth == cpu.read_depth()).all()
+
+
+def test_overlapped_frames_keep_their_own_output():
+    """Frames in flight overlap (geometry of N+1 beside the shading of N).  As rank 0 of 2, each of a run
+    of different frames goes to its own external tile buffer without any wait in between; afterwards every
+    buffer must hold exactly what the same frame gives when rendered alone."""
+    import torch
+    from renderer_amd.types import from_translation, from_rotation_y
+    s = c3_grid_10m(width=640, height=384, scale=0.12)
+    vs = VisualServer(s.width, s.height, device=0)
+    vs.set_tile_partition(0, 2)
+    info = vs.tile_info()
+    nbytes = info["n_owned"] * info["tile_px"] ** 2 * 4
+    s.populate(vs)
+    cams = [from_translation((0.6 * (k % 3) - 0.6, 0.3 * (k % 2), -0.5 * (k % 4))) @ from_rotation_y(0.04 * k) for k in range(10)]
+    bufs = [torch.zeros(nbytes, dtype=torch.uint8, device="cuda") for _ in cams]
+    torch.cuda.synchronize()
+    for c, b in zip(cams, bufs):
+        vs.set_camera(c, s.camera)
+        vs.set_tiles_output(b.data_ptr(), b.numel())
+        vs.render()
+    vs.finish()
+    torch.cuda.synchronize()
+    alone = VisualServer(s.width, s.height, device=0)
+    alone.set_tile_partition(0, 2)
+    s.populate(alone)
+    one = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    alone.set_tiles_output(one.data_ptr(), one.numel())
+    distinct = set()
+    for k, c in enumerate(cams):
+        alone.set_camera(c, s.camera)
+        alone.render()
+        alone.finish()
+        torch.cuda.synchronize()
+        assert torch.equal(one, bufs[k]), f"frame {k} differs from the same frame rendered alone"
+        distinct.add(int(one.to(torch.int64).sum().item()))
+    assert len(distinct) >= 6          # the frames really differ from each other

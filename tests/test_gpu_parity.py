@@ -501,3 +501,69 @@ def test_degenerate_and_nonfinite_geometry():
     gpu, cpu = render_pair(s)
     assert_parity(gpu, cpu, min_covered=int(0.9 * w * h))
     assert np.isfinite(gpu.read_color_hdr()).all()
+
+
+def test_pipelined_frames_do_not_mix():
+    """Consecutive frames overlap on the GPU (geometry of frame N+1 beside the shading of frame N, with
+    the buffers between the two phases kept twice).  Frames that differ - camera, instance transforms,
+    light set, a shadowed light coming and going - are enqueued back to back without waiting; every one
+    is fetched straight after its successor has been enqueued and must equal the same frame rendered alone."""
+    w, h = 256, 160
+    s = soup_scene(91, w, h, n_meshes=4, n_tri=80, lights=3)
+
+    def apply(vs, handles, k):
+        vs.set_camera(from_translation((0.1 * (k % 3), 0.05 * (k % 2), -1.0 - 0.1 * (k % 4))) @ from_rotation_y(0.05 * (k % 5)), s.camera)
+        for n, (nid, t, m) in enumerate(s.instances):
+            vs.set_mesh_instance(nid, from_translation((0.02 * ((k + n) % 3), 0, 0)) @ t, handles[m])
+        for lid, t, light in s.lights:
+            if light.kind_id() == 1 or k % 3 != 1:        # the directional light (shadow cascades) every third frame off
+                vs.set_light(lid, from_rotation_y(0.03 * k) @ t, light)
+
+    def fresh(k):
+        vs = VisualServer(w, h, device=0)
+        handles = s.populate(vs)
+        if k % 3 == 1:
+            vs.reset_scene()
+            handles = [vs.asset_server.add(m) for m in s.meshes]
+        apply(vs, handles, k)
+        vs.render()
+        return vs.read_color_rgba8(), vs.read_depth()
+
+    vs = VisualServer(w, h, device=0)
+    handles = s.populate(vs)
+    n = 9
+    got = []
+    for k in range(n):
+        if k % 3 == 1:            # drop the directional light: rebuild the scene without it
+            vs.reset_scene()
+            handles = [vs.asset_server.add(m) for m in s.meshes]
+        elif k % 3 == 2:
+            pass
+        apply(vs, handles, k)
+        vs.render()
+        vs.render()               # the same frame twice: both parities hold it, the second overlaps the first
+        got.append((vs.read_color_rgba8(), vs.read_depth()))
+    for k in range(n):
+        img, depth = fresh(k)
+        assert (got[k][1].view(np.uint32) == depth.view(np.uint32)).all(), k
+        assert (got[k][0] == img).all(), k
+
+
+def test_pipelined_frames_last_frame_wins():
+    """Many frames in flight (no read-back in between): the frame read at the end is the last one."""
+    w, h = 320, 200
+    s = soup_scene(92, w, h, n_meshes=4, n_tri=80, lights=3)
+    s.lights = [l for l in s.lights if l[2].kind_id() == 1]
+    vs = VisualServer(w, h, device=0)
+    s.populate(vs)
+    cams = [from_translation((0.2 * (k % 3) - 0.2, 0.0, -1.0 - 0.2 * (k % 2))) for k in range(12)]
+    for c in cams:
+        vs.set_camera(c, s.camera)
+        vs.render()
+    img, depth, ids = vs.read_color_rgba8(), vs.read_depth(), vs.read_triangle_ids()
+    alone = VisualServer(w, h, device=0)
+    s.populate(alone)
+    alone.set_camera(cams[-1], s.camera)
+    alone.render()
+    assert (alone.read_triangle_ids() == ids).all() and (alone.read_depth().view(np.uint32) == depth.view(np.uint32)).all()
+    assert (alone.read_color_rgba8() == img).all()
