@@ -231,8 +231,9 @@ private:
     hipEvent_t geo_done_[2] = {}, shade_done_[2] = {};
     uint32_t parity_ = 0;              // buffers of the last enqueued frame
     bool overlap_ = true;              // RND_OVERLAP=0: everything on stream_
+    hipStream_t last_geo_stream_ = nullptr;   // where the previous frame's geometry ran (the two modes can alternate)
+    bool have_timings_ = false;        // timings_ holds a measured frame
     bool serialize_next_ = false;      // the previous frame recorded timing events: keep this one's geometry off its shading
-    bool last_had_sets_ = false;       // the previous frame's shading reads the shadow layers
     DeviceBuffer<uint8_t> d_tables_[2];             // per-frame tables (items, bases, lights, shadow items and sets), one upload
     DeviceBuffer<float4> d_clip_[2];
     DeviceBuffer<SnapVert> d_snap_;
@@ -242,7 +243,7 @@ private:
     uint32_t n_counter_sets_ = 1, h_counter_sets_ = 0;
     // shadow cascades of the directional lights
     DeviceBuffer<TileRef> d_shadow_order_;
-    std::vector<DeviceBuffer<uint64_t>> shadow_layers_;   // per shadowed light: kShadowCascades visibility buffers
+    std::vector<DeviceBuffer<uint64_t>> shadow_layers_[2];   // per frame parity and shadowed light: kShadowCascades visibility buffers
     DeviceBuffer<TileRef> d_launch_order_;
     DeviceBuffer<uint64_t> d_vis_[2];
     DeviceBuffer<uint8_t> d_frame_, d_tiles_;
@@ -259,6 +260,7 @@ private:
     // pinned staging ring for the per-frame tables
     struct Staging {
         void* host = nullptr;
+        void* host_dev = nullptr;     // the same block as the device addresses it (hipHostGetDevicePointer)
         size_t bytes = 0;
         hipEvent_t done = nullptr;
         bool in_flight = false;
