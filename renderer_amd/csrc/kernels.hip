@@ -19,6 +19,9 @@
 
 #include "kernels.h"
 
+#ifndef RND_SCALAR_LIGHTS
+#define RND_SCALAR_LIGHTS 1
+#endif
 #ifndef RND_EARLY_Z
 #define RND_EARLY_Z 0
 #endif
@@ -1508,12 +1511,25 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(
             for (unsigned long long km = __ballot(keep); km; km &= km - 1ull) {
                 // the whole light at once (16 B LDS reads, one wait) rather than field by field as the
                 // branches below get to them
+#if RND_SCALAR_LIGHTS
+                // the surviving light's index is wave-uniform: its 64 bytes come through one scalar load
+                typedef const __attribute__((address_space(4))) GpuLight* cptr_light;
+                const uint32_t li = __builtin_amdgcn_readfirstlane(group + (uint32_t)(__ffsll((long long)km) - 1));
+                cptr_light lp = (cptr_light)fb.lights + li;
+                GpuLight L;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { L.pos[c] = lp->pos[c]; L.dir[c] = lp->dir[c]; }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) L.color[c] = lp->color[c];
+                L.radius = lp->radius; L.kind = lp->kind; L.shadow_index = lp->shadow_index; L.inv_radius = lp->inv_radius;
+#else
                 GpuLight L;
                 {
                     const uint4* src = reinterpret_cast<const uint4*>(&s_lights[group + (uint32_t)(__ffsll((long long)km) - 1)]);
                     uint4* dst = reinterpret_cast<uint4*>(&L);
                     dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
                 }
+#endif
 #if RND_FAST_SHADE
                 if constexpr (PPT == 2) { add_light_pair<kShadows>(L, pp, fb.shadow_sets, fc); continue; }
 #endif
