@@ -66,3 +66,48 @@ def test_visual_server_raises_without_gpu():
     from renderer_amd import RndError, VisualServer
     with pytest.raises(RndError):
         VisualServer(64, 64)
+
+
+def test_rust_sys_crate_declares_the_header():
+    """integration/rust/rnd-sys/src/lib.rs is hand-written (no bindgen here): it must name every entry
+    point of include/rnd.h, and nothing the header does not have."""
+    text = open(os.path.join(ROOT, "integration", "rust", "rnd-sys", "src", "lib.rs")).read()
+    declared = set(re.findall(r"pub fn (rnd_[a-z0-9_]+)\s*\(", text))
+    header = set(header_functions())
+    assert declared == header, (sorted(header - declared), sorted(declared - header))
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """A C99 translation unit that includes rnd.h compiles with -pedantic -Werror, links against the
+    product library and gets the documented error convention from rnd_create without a GPU (or a
+    context with one)."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "consumer.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "rnd.h"
+int main(void) {
+    rnd_ctx* ctx = NULL;
+    rnd_uibox box = {{0.0f, 0.0f}, {1.0f, 1.0f}, {1.0f, 1.0f, 1.0f, 1.0f}};
+    rnd_timings t; rnd_frame_stats s; rnd_vertex v; rnd_submesh_desc d;
+    int rc = rnd_create(&ctx, 0u, 0u, 0);                 /* bad size: must fail, with a message */
+    (void)box; (void)t; (void)s; (void)v; (void)d;
+    if (rc != RND_ERR_INVALID || ctx != NULL || strlen(rnd_last_error(NULL)) == 0) return 1;
+    if (strcmp(rnd_backend_name(), "hip-gfx950") != 0) return 2;
+    rc = rnd_create(&ctx, 64u, 64u, 0);
+    if (rc == RND_OK) { rnd_destroy(ctx); printf("context\n"); }
+    else if (rc < 0 && strlen(rnd_last_error(NULL)) > 0) printf("no device: %s\n", rnd_last_error(NULL));
+    else return 3;
+    return 0;
+}
+''')
+    lib_dir = os.path.dirname(_capi.product_library_path())
+    exe = tmp_path / "consumer"
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           str(src), "-o", str(exe), "-L", lib_dir, "-lrnd_amd", f"-Wl,-rpath,{lib_dir}"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
