@@ -13,6 +13,7 @@
 // fixed order (compiled with -ffp-contract=off; f32 divide and sqrt are correctly rounded by
 // hipcc's default), as DESIGN.md "Raster rules" states it, so results are reproducible bit for bit.
 #include <cstdlib>
+#include <type_traits>
 
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
@@ -941,25 +942,37 @@ __global__ __launch_bounds__(256) void k_bin_fill(FrameBuffers fb, Capacities ca
 // lane each with 32-bit edge functions; the rest are queued in LDS and swept by a whole wave in
 // 8x8 pixel blocks with 64-bit edge functions.
 // ------------------------------------------------------------------------------------------
-template <bool kAlpha>
+// kNarrow: the record's bbox is below 64 px (flag bit 0), so every factor of the edge functions fits the
+// full-rate 24-bit multiply and 32-bit sums (as in raster_small); otherwise 64-bit arithmetic.  Medium
+// triangles (tens of pixels, the bulk of real content) are narrow: with 64-bit edges this sweep was
+// 200 wave instructions per bin entry and made k_raster VALU-bound (C2 at 8K).
+template <bool kAlpha, bool kNarrow>
 __device__ __forceinline__ void raster_wave(const SetupRecord& r, int32_t i0, int32_t i1, int32_t j0, int32_t j1,
                                             const LdsSink& sink, const FrameBuffers& fb, FrameConstRef fc) {
+    typedef typename std::conditional<kNarrow, int32_t, long long>::type edge_t;
     const uint32_t lane = lane_id();
     const int32_t lx = (int32_t)(lane & 7u), ly = (int32_t)(lane >> 3);
     const int32_t ex0 = r.x1 - r.x2, ey0 = r.y1 - r.y2;
     const int32_t ex1 = r.x2 - r.x0, ey1 = r.y2 - r.y0;
     const int32_t ex2 = r.x0 - r.x1, ey2 = r.y0 - r.y1;
-    const long long b0 = ((-ey0 > 0) || (ey0 == 0 && ex0 > 0)) ? 0 : 1;
-    const long long b1 = ((-ey1 > 0) || (ey1 == 0 && ex1 > 0)) ? 0 : 1;
-    const long long b2 = ((-ey2 > 0) || (ey2 == 0 && ex2 > 0)) ? 0 : 1;
+    const edge_t b0 = ((-ey0 > 0) || (ey0 == 0 && ex0 > 0)) ? 0 : 1;
+    const edge_t b1 = ((-ey1 > 0) || (ey1 == 0 && ex1 > 0)) ? 0 : 1;
+    const edge_t b2 = ((-ey2 > 0) || (ey2 == 0 && ex2 > 0)) ? 0 : 1;
     for (int32_t by = j0; by <= j1; by += 8)
         for (int32_t bx = i0; bx <= i1; bx += 8) {
             int32_t i = bx + lx, j = by + ly;
             if (i > i1 || j > j1) continue;
             int32_t px = i * kSub + kSub / 2, py = j * kSub + kSub / 2;
-            long long w0 = (long long)ex0 * (py - r.y2) - (long long)ey0 * (px - r.x2);
-            long long w1 = (long long)ex1 * (py - r.y0) - (long long)ey1 * (px - r.x0);
-            long long w2 = (long long)ex2 * (py - r.y1) - (long long)ey2 * (px - r.x1);
+            edge_t w0, w1, w2;
+            if constexpr (kNarrow) {
+                w0 = __mul24(ex0, py - r.y2) - __mul24(ey0, px - r.x2);
+                w1 = __mul24(ex1, py - r.y0) - __mul24(ey1, px - r.x0);
+                w2 = __mul24(ex2, py - r.y1) - __mul24(ey2, px - r.x1);
+            } else {
+                w0 = (long long)ex0 * (py - r.y2) - (long long)ey0 * (px - r.x2);
+                w1 = (long long)ex1 * (py - r.y0) - (long long)ey1 * (px - r.x0);
+                w2 = (long long)ex2 * (py - r.y1) - (long long)ey2 * (px - r.x1);
+            }
             if (w0 >= b0 && w1 >= b1 && w2 >= b2) {
                 float l1 = (float)w1 * r.inv_area, l2 = (float)w2 * r.inv_area;
                 float z = (l1 * r.dz1 + l2 * r.dz2) + r.z0;
@@ -982,8 +995,18 @@ template <bool kAlpha>
 __global__ __launch_bounds__(256) void k_raster(FrameBuffers fb, Capacities cap) {
     FrameConstRef fc = frame_const_ref(fb.frame_const);
     __shared__ unsigned long long s_vis[kTilePixels];
-    __shared__ uint32_t s_big[256];
-    __shared__ uint32_t s_nbig;
+    // the batch's triangles that a whole wave sweeps, kept in LDS by the lanes that classified them: a
+    // second fetch of the record per triangle from global memory made the sweep a queue of ~1 us round
+    // trips (C2 at 8K, ~37 bin entries of ~70 px per tile: 13 us per tile, 0.41 ms per frame)
+    __shared__ float4 s_big[256][3];
+    // two classes share s_big: "medium" triangles (narrow, at most 255 pixel centres inside this tile) fill it
+    // from the front and are dealt kMediumLanes lanes each with the direct-raster pixel walk (exact bbox, no
+    // 8x8 granularity, no per-block edge set-up); the rest fill it from the back and are swept by a whole wave
+    __shared__ uint32_t s_nmed, s_nlarge;
+#ifndef RND_MEDIUM_LANES
+#define RND_MEDIUM_LANES 16
+#endif
+    constexpr uint32_t kMediumLanes = RND_MEDIUM_LANES;
     const uint32_t tid = threadIdx.x;
     const uint32_t tile = fb.launch_order[blockIdx.x].tile;
     const int32_t tile_x0 = (int32_t)((tile % fc.tiles_x) * kTile), tile_y0 = (int32_t)((tile / fc.tiles_x) * kTile);
@@ -997,7 +1020,7 @@ __global__ __launch_bounds__(256) void k_raster(FrameBuffers fb, Capacities cap)
     const LdsSink sink{s_vis, tile_x0, tile_y0};
     __syncthreads();
     for (uint32_t b = 0; b < n; b += 256u) {
-        if (tid == 0) s_nbig = 0;
+        if (tid == 0) { s_nmed = 0; s_nlarge = 0; }
         __syncthreads();
         uint32_t e = b + tid;
         if (e < n) {
@@ -1013,20 +1036,48 @@ __global__ __launch_bounds__(256) void k_raster(FrameBuffers fb, Capacities cap)
             if (i0 <= i1 && j0 <= j1) {
                 uint32_t npix = (uint32_t)(i1 - i0 + 1) * (uint32_t)(j1 - j0 + 1);
                 if ((r.flags & 1u) && npix <= kSmallPixels) raster_small<kAlpha>(r, i0, i1, j0, j1, sink, fb, fc);
-                else s_big[atomicAdd(&s_nbig, 1u)] = slot;
+                else {
+                    const bool medium = (r.flags & 1u) && npix <= 255u;
+                    const uint32_t k = medium ? atomicAdd(&s_nmed, 1u) : 255u - atomicAdd(&s_nlarge, 1u);
+                    const float4* src = reinterpret_cast<const float4*>(&r);
+                    s_big[k][0] = src[0]; s_big[k][1] = src[1]; s_big[k][2] = src[2];
+                }
             }
         }
         __syncthreads();
-        const uint32_t nbig = s_nbig;
-        for (uint32_t q = tid >> 6; q < nbig; q += 4u) {
-            SetupRecord r = load_record(fb.records, s_big[q]);
+        const uint32_t nmed = s_nmed, nlarge = s_nlarge;
+        for (uint32_t q = tid / kMediumLanes; q < nmed; q += 256u / kMediumLanes) {
+            SetupRecord r;
+            {
+                float4* dst = reinterpret_cast<float4*>(&r);
+                dst[0] = s_big[q][0]; dst[1] = s_big[q][1]; dst[2] = s_big[q][2];
+            }
+            int32_t xmin = min(r.x0, min(r.x1, r.x2)), xmax = max(r.x0, max(r.x1, r.x2));
+            int32_t ymin = min(r.y0, min(r.y1, r.y2)), ymax = max(r.y0, max(r.y1, r.y2));
+            TileRect tr{0, 0, 0, 0, 0, 0, 0, 0};
+            tr.i0 = max((xmin - kSub / 2 + kSub - 1) >> kSubpixelBits, tile_x0);
+            tr.i1 = min((xmax - kSub / 2) >> kSubpixelBits, tile_x1);
+            tr.j0 = max((ymin - kSub / 2 + kSub - 1) >> kSubpixelBits, tile_y0);
+            tr.j1 = min((ymax - kSub / 2) >> kSubpixelBits, tile_y1);
+            const DirectTri dt = make_direct(r, tr);
+            const uint32_t npix = (dt.shape >> 8) & 255u;
+            for (uint32_t k = tid % kMediumLanes; k < npix; k += kMediumLanes) direct_pixel<kAlpha>(dt, k, sink, fb, fc);
+        }
+        for (uint32_t q = tid >> 6; q < nlarge; q += 4u) {
+            SetupRecord r;
+            {
+                float4* dst = reinterpret_cast<float4*>(&r);
+                const uint32_t at = 255u - q;
+                dst[0] = s_big[at][0]; dst[1] = s_big[at][1]; dst[2] = s_big[at][2];
+            }
             int32_t xmin = min(r.x0, min(r.x1, r.x2)), xmax = max(r.x0, max(r.x1, r.x2));
             int32_t ymin = min(r.y0, min(r.y1, r.y2)), ymax = max(r.y0, max(r.y1, r.y2));
             int32_t i0 = max((xmin - kSub / 2 + kSub - 1) >> kSubpixelBits, tile_x0);
             int32_t i1 = min((xmax - kSub / 2) >> kSubpixelBits, tile_x1);
             int32_t j0 = max((ymin - kSub / 2 + kSub - 1) >> kSubpixelBits, tile_y0);
             int32_t j1 = min((ymax - kSub / 2) >> kSubpixelBits, tile_y1);
-            raster_wave<kAlpha>(r, i0, i1, j0, j1, sink, fb, fc);
+            if (r.flags & 1u) raster_wave<kAlpha, true>(r, i0, i1, j0, j1, sink, fb, fc);
+            else raster_wave<kAlpha, false>(r, i0, i1, j0, j1, sink, fb, fc);
         }
         __syncthreads();
     }
