@@ -159,6 +159,12 @@ int rnd_set_mesh_instance(rnd_ctx* ctx, uint64_t id, const float transform_cols[
  * reference only sets through set_sprite (:539-548). */
 int rnd_set_mesh_instance_ex(rnd_ctx* ctx, uint64_t id, const float transform_cols[16],
                              uint32_t mesh_id, uint32_t material_override, uint32_t casts_shadows);
+/* The same for n instances in one call (the engine re-submits every node every frame,
+ * engine.rs:136-143; a binding can hand the whole list over at once): ids[n], 16 floats per transform,
+ * mesh_ids[n]; material_override none, casts_shadows true.  Stops at the first error.  No counterpart in
+ * the reference. */
+int rnd_set_mesh_instances(rnd_ctx* ctx, uint32_t n, const uint64_t* ids, const float* transforms_cols,
+                           const uint32_t* mesh_ids);
 /* reference: set_sprite(id, Affine3A, Handle<Image>, Color, ..) :508-550 — unit quad, billboard
  * On, unlit, no shadows, base colour = `color`, texture = texture_id (RND_NONE = white). */
 int rnd_set_sprite(rnd_ctx* ctx, uint64_t id, const float transform_cols[16], uint32_t texture_id,

@@ -112,6 +112,7 @@ extern "C" {
     pub fn rnd_frame_stats_get(ctx: *mut rnd_ctx, out: *mut rnd_frame_stats) -> c_int;
 
     pub fn rnd_set_tile_partition(ctx: *mut rnd_ctx, rank: u32, world: u32) -> c_int;
+    pub fn rnd_set_mesh_instances(ctx: *mut rnd_ctx, n: u32, ids: *const u64, transforms_cols: *const f32, mesh_ids: *const u32) -> c_int;
     pub fn rnd_set_uiboxes(ctx: *mut rnd_ctx, n: u32, boxes: *const rnd_uibox) -> c_int;
     pub fn rnd_set_font_image(ctx: *mut rnd_ctx, width: u32, height: u32, rgba8: *const u8) -> c_int;
     pub fn rnd_reset_texts(ctx: *mut rnd_ctx) -> c_int;

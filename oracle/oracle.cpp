@@ -1198,6 +1198,13 @@ int orc_set_mesh_instance_ex(rnd_ctx* ctx, uint64_t id, const float t[16], uint3
 int orc_set_mesh_instance(rnd_ctx* ctx, uint64_t id, const float t[16], uint32_t mesh) {
     return orc_set_mesh_instance_ex(ctx, id, t, mesh, RND_NONE, 1);
 }
+int orc_set_mesh_instances(rnd_ctx* ctx, uint32_t n, const uint64_t* ids, const float* t, const uint32_t* meshes) {
+    for (uint32_t k = 0; k < n; ++k) {
+        int rc = orc_set_mesh_instance_ex(ctx, ids[k], t + 16 * (size_t)k, meshes[k], RND_NONE, 1);
+        if (rc != RND_OK) return rc;
+    }
+    return RND_OK;
+}
 int orc_set_sprite(rnd_ctx* ctx, uint64_t id, const float t[16], uint32_t tex, const float color[4]) {
     Ctx* c = CTX(ctx);
     if (!t || !color) { c->err = "bad sprite"; return RND_ERR_INVALID; }

@@ -91,6 +91,7 @@ SIGNATURES = {
     "set_light": (C.c_int, [_P, C.c_uint64, _F16, _F16, C.c_uint32, C.c_float]),
     "set_mesh_instance": (C.c_int, [_P, C.c_uint64, _F16, C.c_uint32]),
     "set_mesh_instance_ex": (C.c_int, [_P, C.c_uint64, _F16, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "set_mesh_instances": (C.c_int, [_P, C.c_uint32, _P, _P, _P]),
     "set_sprite": (C.c_int, [_P, C.c_uint64, _F16, C.c_uint32, _F16]),
     "reset_scene": (C.c_int, [_P]),
     "set_uiboxes": (C.c_int, [_P, C.c_uint32, _P]),

@@ -141,6 +141,12 @@ int rnd_set_sprite(rnd_ctx* ctx, uint64_t id, const float t[16], uint32_t textur
     REQUIRE(ctx, t && color, "null transform or colour");
     return guard(ctx, [&](rnd::VisualServer& v) { v.set_sprite(id, rnd::Mat4::from_cols_array(t), texture_id, color); });
 }
+int rnd_set_mesh_instances(rnd_ctx* ctx, uint32_t n, const uint64_t* ids, const float* transforms_cols, const uint32_t* mesh_ids) {
+    REQUIRE(ctx, !n || (ids && transforms_cols && mesh_ids), "null instance arrays");
+    return guard(ctx, [&](rnd::VisualServer& v) {
+        for (uint32_t k = 0; k < n; ++k) v.set_mesh_instance(ids[k], rnd::Mat4::from_cols_array(transforms_cols + 16 * (size_t)k), mesh_ids[k], RND_NONE, true);
+    });
+}
 int rnd_reset_scene(rnd_ctx* ctx) { return guard(ctx, [&](rnd::VisualServer& v) { v.reset_scene(); }); }
 
 int rnd_set_uiboxes(rnd_ctx* ctx, uint32_t n, const rnd_uibox* boxes) { return guard(ctx, [&](rnd::VisualServer& v) { v.set_uiboxes(n, boxes); }); }

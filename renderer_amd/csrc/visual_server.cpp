@@ -324,7 +324,8 @@ void VisualServer::set_light(UniqueNodeId id, const Mat4& transform, const Light
     RenderLight rl{id, transform, l, {}};
     // create_light / update_light recompute the cascades from the camera current at the call
     // (visual_server.rs:380-381, :445-446); set_camera does not (:221 FIXME)
-    shadow_cascade_projviews(inv_projection_view_, transform.axis(2), rl.cascades);
+    // (only directional lights ever read theirs: render_mesh.wgsl:150-152)
+    if (l.kind == RND_LIGHT_DIRECTIONAL) shadow_cascade_projviews(inv_projection_view_, transform.axis(2), rl.cascades);
     for (auto& e : lights_)
         if (e.id == id) { e = rl; return; }
     if (lights_.size() >= kMaxLights) throw Error(RND_ERR_INVALID, "too many lights (max 256)");
@@ -336,8 +337,9 @@ void VisualServer::set_mesh_instance(UniqueNodeId id, const Mat4& transform, uin
     if (!meshes_.count(mesh_id)) throw Error(RND_ERR_UNKNOWN_ID, "mesh id not registered");
     if (material_override != RND_NONE && !materials_.count(material_override)) throw Error(RND_ERR_UNKNOWN_ID, "material id not registered");
     RenderMeshInstance inst{id, transform, mesh_id, material_override, casts_shadows};
-    for (auto& e : mesh_instances_)
-        if (e.id == id) { e = inst; return; }
+    auto found = mesh_instance_index_.find(id);
+    if (found != mesh_instance_index_.end()) { mesh_instances_[found->second] = inst; return; }
+    mesh_instance_index_.emplace(id, (uint32_t)mesh_instances_.size());
     mesh_instances_.push_back(inst);
 }
 
@@ -364,7 +366,7 @@ void VisualServer::reset_scene() {
     }
     for (auto& kv : textures_) kv.second.texels.release();
     textures_.clear();
-    materials_.clear(); lights_.clear(); mesh_instances_.clear(); sprite_materials_.clear();
+    materials_.clear(); lights_.clear(); mesh_instances_.clear(); mesh_instance_index_.clear(); sprite_materials_.clear();
     fullscreen_ = 0;        // RenderScene::fullscreen_texture (visual_server.rs:903)
 }
 
@@ -449,6 +451,11 @@ void VisualServer::build_frame(std::vector<DrawItem>& items, std::vector<uint32_
     const Mat4 pv = projection_ * view_;
     uint64_t vert_base = 0, tri_base = 0, unit_base = 0;
     frame_alpha_test_ = false; frame_textured_ = false;
+    bool any_directional = false;
+    for (const RenderLight& l : lights_) any_directional = any_directional || l.light.kind == RND_LIGHT_DIRECTIONAL;
+    const size_t expect = mesh_instances_.size() + 8;
+    items.reserve(expect); vert_bases.reserve(expect + 1); tri_bases.reserve(expect + 1); unit_bases.reserve(expect + 1);
+    if (any_directional) shadow_items.reserve(expect);
     // for mesh_instance { for submesh } — visual_server.rs:227-245
     for (const RenderMeshInstance& inst : mesh_instances_) {
         const RenderMesh& mesh = meshes_.at(inst.mesh);
@@ -501,10 +508,12 @@ void VisualServer::build_frame(std::vector<DrawItem>& items, std::vector<uint32_
             // the same geometry as the shadow passes draw it (render_shadow_map.wgsl:25-33: model matrix
             // only, no billboard modes; pipeline3d.rs:268-313: no fragment stage, so no alpha test;
             // instances with casts_shadows = false are skipped)
-            DrawItem sd = d;
-            inst.transform.to_cols_array(sd.world);
-            sd.flags = inst.casts_shadows ? 0u : kItemSkip;
-            shadow_items.push_back(sd);
+            if (any_directional) {
+                DrawItem sd = d;
+                inst.transform.to_cols_array(sd.world);
+                sd.flags = inst.casts_shadows ? 0u : kItemSkip;
+                shadow_items.push_back(sd);
+            }
         }
     }
     vert_bases.push_back((uint32_t)vert_base);

@@ -202,6 +202,7 @@ private:
     void upload_texture_table();
     std::vector<RenderLight> lights_;
     std::vector<RenderMeshInstance> mesh_instances_;
+    std::unordered_map<UniqueNodeId, uint32_t> mesh_instance_index_;     // id -> position in mesh_instances_ (draw order = insertion order)
     std::unordered_map<UniqueNodeId, uint32_t> sprite_materials_;
     uint32_t next_sprite_material_ = 0x80000000u;
 

@@ -173,6 +173,19 @@ class VisualServer:
             mat = RND_NONE if material_override is None else int(material_override)
             self._check(self.api.set_mesh_instance_ex(self._ctx, int(id), _fp(t), mid, mat, 1 if casts_shadows else 0))
 
+    def set_mesh_instances(self, ids, transforms, mesh_handles):
+        """n instances in one call (rnd_set_mesh_instances): ids (n,), transforms (n, 4, 4) as the
+        per-instance call takes them, one mesh handle or a sequence of n."""
+        ids = np.ascontiguousarray(ids, dtype=np.uint64)
+        n = len(ids)
+        cols = np.ascontiguousarray(np.stack([to_cols_array(t) for t in transforms]).astype(np.float32)) if n else np.zeros((0, 16), np.float32)
+        if isinstance(mesh_handles, Handle):
+            meshes = np.full(n, self.register_mesh(mesh_handles), dtype=np.uint32)
+        else:
+            meshes = np.ascontiguousarray([self.register_mesh(h) for h in mesh_handles], dtype=np.uint32)
+        self._check(self.api.set_mesh_instances(self._ctx, n, ids.ctypes.data if n else None, cols.ctypes.data if n else None,
+                                                meshes.ctypes.data if n else None))
+
     def set_sprite(self, id, transform, image_handle, base_color: Color, asset_server=None):
         """visual_server.rs:508-550"""
         if asset_server is not None:

@@ -147,3 +147,31 @@ def test_detile_numpy():
         tiles[k] = k + 1
     detile_numpy(frame, tiles, list(range(tx * ty)), tp, tx)
     assert frame[0, 0, 0] == 1 and frame[0, 69, 0] == 3 and frame[44, 0, 0] == 4 and frame[44, 69, 0] == 6
+
+
+def test_batched_instances_equal_single_calls():
+    """rnd_set_mesh_instances is the per-instance call in a loop: same draw order, same
+    update-in-place by id - checked on the oracle, which shares the entry point's contract."""
+    import numpy as np
+    from renderer_amd.types import Camera, Mesh, from_scale, from_translation, identity
+    from tests.helpers import oracle_server
+    rng = np.random.default_rng(5)
+    ids = np.arange(1, 41, dtype=np.uint64)
+    ts = [from_translation(tuple(rng.uniform((-2, -1.5, 2), (2, 1.5, 6)))) @ from_scale((0.4, 0.4, 1)) for _ in ids]
+    imgs = []
+    for batched in (False, True):
+        vs = oracle_server(96, 64, threads=2)
+        vs.set_camera(identity(), Camera(aspect_ratio=1.5))
+        h = vs.asset_server.add(Mesh.quad())
+        if batched:
+            vs.set_mesh_instances(ids, ts, h)
+            vs.set_mesh_instances(ids[:5], ts[5:10], h)          # update in place: order unchanged
+        else:
+            for i, t in zip(ids, ts):
+                vs.set_mesh_instance(int(i), t, h)
+            for i, t in zip(ids[:5], ts[5:10]):
+                vs.set_mesh_instance(int(i), t, h)
+        vs.render()
+        imgs.append((vs.read_triangle_ids(), vs.read_depth()))
+    assert (imgs[0][0] == imgs[1][0]).all() and (imgs[0][1] == imgs[1][1]).all()
+    assert (imgs[0][0] != 0xFFFFFFFF).sum() > 500

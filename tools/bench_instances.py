@@ -32,6 +32,22 @@ vs.finish()
 t2 = time.perf_counter()
 mean, _ = vs.mean_timings()
 print(f"{m} {kind} instances: {steps / (t2 - t0):.1f} frames/s, host enqueue {(t1 - t0) / steps * 1e3:.3f} ms/frame", {k: round(v, 4) for k, v in mean.items()})
+# the same frames with the instance list handed over in one call
+import ctypes as C
+ids = np.array([a[0].value for a in drv.instances], dtype=np.uint64)
+cols = np.ascontiguousarray(np.stack([np.ctypeslib.as_array(a[1], shape=(16,)) for a in drv.instances]).astype(np.float32))
+meshes = np.array([a[2].value for a in drv.instances], dtype=np.uint32)
+t0 = time.perf_counter()
+for _ in range(steps):
+    vs.api.set_camera(vs._ctx, *drv.cam_args)
+    for a in drv.lights:
+        vs.api.set_light(vs._ctx, *a)
+    vs.api.set_mesh_instances(vs._ctx, len(ids), ids.ctypes.data, cols.ctypes.data, meshes.ctypes.data)
+    vs.api.render(vs._ctx)
+t1 = time.perf_counter()
+vs.finish()
+t2 = time.perf_counter()
+print(f"  batched rnd_set_mesh_instances: {steps / (t2 - t0):.1f} frames/s, host enqueue {(t1 - t0) / steps * 1e3:.3f} ms/frame")
 t0 = time.perf_counter()
 for _ in range(20):
     vs.api.render(vs._ctx)
