@@ -1000,29 +1000,39 @@ __device__ __forceinline__ void raster_wave(const SetupRecord& r, int32_t i0, in
     const edge_t b0 = ((-ey0 > 0) || (ey0 == 0 && ex0 > 0)) ? 0 : 1;
     const edge_t b1 = ((-ey1 > 0) || (ey1 == 0 && ex1 > 0)) ? 0 : 1;
     const edge_t b2 = ((-ey2 > 0) || (ey2 == 0 && ex2 > 0)) ? 0 : 1;
-    for (int32_t by = j0; by <= j1; by += 8)
+    // The lane's edge functions at its pixel of the first block; from block to block they move by whole
+    // multiples of the coefficients (exact integer arithmetic: the same values as evaluating them anew,
+    // which cost seven instructions per edge and block instead of one).  Lanes past i1 / j1 run up to 7
+    // pixels outside the bbox: for narrow records that still fits 32 bits (factors below 2^15 + 2^11).
+    const int32_t px = (i0 + lx) * kSub + kSub / 2, py = (j0 + ly) * kSub + kSub / 2;
+    edge_t r0, r1, r2;
+    if constexpr (kNarrow) {
+        r0 = __mul24(ex0, py - r.y2) - __mul24(ey0, px - r.x2);
+        r1 = __mul24(ex1, py - r.y0) - __mul24(ey1, px - r.x0);
+        r2 = __mul24(ex2, py - r.y1) - __mul24(ey2, px - r.x1);
+    } else {
+        r0 = (long long)ex0 * (py - r.y2) - (long long)ey0 * (px - r.x2);
+        r1 = (long long)ex1 * (py - r.y0) - (long long)ey1 * (px - r.x0);
+        r2 = (long long)ex2 * (py - r.y1) - (long long)ey2 * (px - r.x1);
+    }
+    const edge_t sx0 = (edge_t)ey0 * (8 * kSub), sx1 = (edge_t)ey1 * (8 * kSub), sx2 = (edge_t)ey2 * (8 * kSub);   // per block column (subtracted)
+    const edge_t sy0 = (edge_t)ex0 * (8 * kSub), sy1 = (edge_t)ex1 * (8 * kSub), sy2 = (edge_t)ex2 * (8 * kSub);   // per block row
+    for (int32_t by = j0; by <= j1; by += 8) {
+        edge_t w0 = r0, w1 = r1, w2 = r2;
+        const int32_t j = by + ly;
         for (int32_t bx = i0; bx <= i1; bx += 8) {
-            int32_t i = bx + lx, j = by + ly;
-            if (i > i1 || j > j1) continue;
-            int32_t px = i * kSub + kSub / 2, py = j * kSub + kSub / 2;
-            edge_t w0, w1, w2;
-            if constexpr (kNarrow) {
-                w0 = __mul24(ex0, py - r.y2) - __mul24(ey0, px - r.x2);
-                w1 = __mul24(ex1, py - r.y0) - __mul24(ey1, px - r.x0);
-                w2 = __mul24(ex2, py - r.y1) - __mul24(ey2, px - r.x1);
-            } else {
-                w0 = (long long)ex0 * (py - r.y2) - (long long)ey0 * (px - r.x2);
-                w1 = (long long)ex1 * (py - r.y0) - (long long)ey1 * (px - r.x0);
-                w2 = (long long)ex2 * (py - r.y1) - (long long)ey2 * (px - r.x1);
-            }
-            if (w0 >= b0 && w1 >= b1 && w2 >= b2) {
+            const int32_t i = bx + lx;
+            if (i <= i1 && j <= j1 && w0 >= b0 && w1 >= b1 && w2 >= b2) {
                 float l1 = (float)w1 * r.inv_area, l2 = (float)w2 * r.inv_area;
                 float z = (l1 * r.dz1 + l2 * r.dz2) + r.z0;
                 bool pass = true;
                 if constexpr (kAlpha) pass = !(r.flags & 2u) || alpha_pass(fb, fc, r.tri_id, (uint32_t)i, (uint32_t)j);
                 if (pass) sink(i, j, z, r.tri_id);
             }
+            w0 -= sx0; w1 -= sx1; w2 -= sx2;
         }
+        r0 += sy0; r1 += sy1; r2 += sy2;
+    }
 }
 
 __device__ __forceinline__ SetupRecord load_record(const SetupRecord* __restrict__ recs, uint32_t slot) {
