@@ -9,6 +9,8 @@ namespace rnd {
 constexpr uint32_t kTile = 32;                 // square screen tile edge in pixels
 constexpr uint32_t kTilePixels = kTile * kTile;
 constexpr uint32_t kDirectPixels = 32;        // K2a rasterizes a triangle itself when its bbox holds at most this many pixel centres (RND_DIRECT_PIXELS, <= 64)
+constexpr uint32_t kWideListTiles = 256;      // a record touching more tiles than this AND an eighth of the frame's is not binned but put on the wide list (floors, walls, sky)
+constexpr uint32_t kWideListCap = 65536;
 constexpr uint32_t kOwnerGroup = 4;            // sort-first ownership: full-width stripes of this many tile rows, dealt round-robin
 constexpr int kSubpixelBits = 8;
 constexpr int kSub = 1 << kSubpixelBits;       // 256 sub-pixel steps per pixel
@@ -175,13 +177,14 @@ struct FrameCounters {
     uint32_t n_valid;          // valid setup records (statistics)
     uint32_t n_active;         // work units that survived k_cull
     uint32_t all_verts;        // a surviving unit uses a wide vertex range: transform every vertex block
-    uint32_t pad[1];
+    uint32_t n_wide;           // records on the wide list (not binned: every tile's raster workgroup checks them)
 };
 
 struct Capacities {
     uint32_t records;       // slots in the record stream: setup_slots + room for the clipper's records
     uint32_t clip_queue, entries;
     uint32_t setup_slots;   // slots addressed by k_setup: kChunkTris per work unit
+    uint32_t wide_list;     // entries of the wide-record list
 };
 
 }  // namespace rnd

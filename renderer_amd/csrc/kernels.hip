@@ -535,9 +535,29 @@ __device__ __forceinline__ void walk_rects(bool has, uint32_t tx0, uint32_t ty0,
     }
 }
 
-__device__ __forceinline__ uint32_t count_wave(bool emit, const TileRect& t, FrameConstRef fc,
+constexpr uint32_t kWidePos = 0xFFFFFFFEu;      // tileword.y of a record that is on the wide list instead of in bins
+
+// A record that touches more than kWideListTiles tiles is not binned at all: its slot goes on a short
+// list that every tile's raster workgroup checks against its own position.  (Binning one
+// screen-filling triangle at 4K meant 8160 returning atomics by a single wave: 50 us.)  When the list
+// is full the record is binned like any other.
+__device__ __forceinline__ bool push_wide(bool candidate, const TileRect& t, uint32_t slot, FrameConstRef fc, FrameCounters* counters,
+                                          uint32_t* __restrict__ wide_list, uint32_t cap_wide) {
+    // every tile pays a look at every wide record, so only rects of at least an eighth of the frame's
+    // tiles qualify (at 4K: a megapixel): with 64 tiles as the bar a soup of 300-pixel triangles put
+    // thousands of records on the list and lost in the raster what it gained in the bin fill
+    const uint32_t bar = max(kWideListTiles, (fc.tiles_x * fc.tiles_y) >> 3);
+    if (!candidate || (t.tx1 - t.tx0 + 1u) * (t.ty1 - t.ty0 + 1u) <= bar) return false;
+    const uint32_t w = atomicAdd(&counters->n_wide, 1u);
+    if (w >= cap_wide) return false;
+    wide_list[w] = slot;
+    return true;
+}
+
+__device__ __forceinline__ uint32_t count_wave(bool emit, const TileRect& t, uint32_t slot, FrameConstRef fc,
                                                uint32_t* __restrict__ count_single,
-                                               uint32_t* __restrict__ count_multi, FrameCounters* counters) {
+                                               uint32_t* __restrict__ count_multi, FrameCounters* counters,
+                                               uint32_t* __restrict__ wide_list, uint32_t cap_wide) {
     const uint32_t lane = lane_id();
     if (emit && !guard(t.tx1 < fc.tiles_x && t.ty1 < fc.tiles_y && t.tx0 <= t.tx1 && t.ty0 <= t.ty1, counters, kGuardCount)) emit = false;
     bool single = emit && t.tx0 == t.tx1 && t.ty0 == t.ty1;
@@ -556,9 +576,10 @@ __device__ __forceinline__ uint32_t count_wave(bool emit, const TileRect& t, Fra
     }
     uint32_t base = __shfl(my_base, my_leader);
     const uint32_t tiles_x = fc.tiles_x;
-    walk_rects(emit && !single, t.tx0, t.ty0, t.tx1, t.ty1, 0u, fc.rank, fc.world,
+    const bool wide = push_wide(emit && !single, t, slot, fc, counters, wide_list, cap_wide);
+    walk_rects(emit && !single && !wide, t.tx0, t.ty0, t.tx1, t.ty1, 0u, fc.rank, fc.world,
                [&](uint32_t tx, uint32_t ty, uint32_t) { atomicAdd(&count_multi[ty * tiles_x + tx], 1u); });
-    return single ? base + my_rank : kNoBinPos;
+    return single ? base + my_rank : (wide ? kWidePos : kNoBinPos);
 }
 
 // Reject / cull / record of one triangle from its three pre-snapped vertices (K1 did the per-vertex
@@ -754,7 +775,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
         if (lane == 0) wave_base = atomicAdd(&s_used, (uint32_t)__popcll(em));
         wave_base = __builtin_amdgcn_readfirstlane(wave_base);
         const uint32_t slot = chunk_base + wave_base + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
-        const uint32_t pos = count_wave(emit, tr, fc, fb.tile_count, fb.tile_count + n_tiles, fb.counters);
+        const uint32_t pos = count_wave(emit, tr, slot, fc, fb.tile_count, fb.tile_count + n_tiles, fb.counters, fb.wide_list, cap.wide_list);
         if (emit && guard(slot < cap.records, fb.counters, kGuardSetup)) {
             float4* dst = reinterpret_cast<float4*>(fb.records + slot);
             const float4* src = reinterpret_cast<const float4*>(&rec);
@@ -852,7 +873,9 @@ __global__ __launch_bounds__(256) void k_clip(FrameBuffers fb, Capacities cap) {
                 else {
                     atomicAdd(&fb.counters->n_valid, 1u);
                     fb.records[slot] = rec;
-                    fb.tilewords[slot] = make_uint2(pack_tileword(tr), kNoBinPos);
+                    const bool wide = push_wide(true, tr, slot, fc, fb.counters, fb.wide_list, cap.wide_list);
+                    fb.tilewords[slot] = make_uint2(pack_tileword(tr), wide ? kWidePos : kNoBinPos);
+                    if (wide) emit = false;      // nothing to count
                 }
             }
             walk_rects(emit, tr.tx0, tr.ty0, tr.tx1, tr.ty1, 0u, fc.rank, fc.world,
@@ -942,6 +965,7 @@ __device__ __forceinline__ void bin_record(const FrameBuffers& fb, FrameConstRef
     if (has) w = fb.tilewords[r];
     const uint32_t tx0 = w.x & 255u, ty0 = (w.x >> 8) & 255u;
     if (has && !guard(tx0 + ((w.x >> 16) & 255u) < fc.tiles_x && ty0 + (w.x >> 24) < fc.tiles_y, fb.counters, kGuardBin)) has = false;
+    if (has && w.y == kWidePos) has = false;        // on the wide list: no bin entries
     if (has && w.y != kNoBinPos) {
         // single-tile record: its position was handed out by the count pass
         const uint32_t tile = ty0 * fc.tiles_x + tx0;
@@ -1066,18 +1090,30 @@ __global__ __launch_bounds__(256) void k_raster(FrameBuffers fb, Capacities cap)
     const int32_t tile_y1 = min(tile_y0 + (int32_t)kTile, (int32_t)fc.height) - 1;
     uint32_t off = fb.tile_offset[tile], n = fb.tile_count[tile] + fb.tile_count[fc.tiles_x * fc.tiles_y + tile];
     if (off >= cap.entries) n = 0; else n = min(n, cap.entries - off);
-    if (n == 0) return;     // nothing binned here: the tile keeps what k_setup's direct path wrote
+    const uint32_t n_wide = min(fb.counters->n_wide, cap.wide_list);
+    if (n == 0 && n_wide == 0) return;     // nothing binned here: the tile keeps what k_setup's direct path wrote
+    const uint32_t my_tx = tile % fc.tiles_x, my_ty = tile / fc.tiles_x;
+    const uint32_t n_all = n + n_wide;     // bin entries, then the wide list (filtered by its records' tile rects)
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(fb.vis) + (size_t)tile * kTilePixels;
     for (uint32_t k = tid; k < kTilePixels; k += 256u) s_vis[k] = dst[k];
     const LdsSink sink{s_vis, tile_x0, tile_y0};
     __syncthreads();
-    for (uint32_t b = 0; b < n; b += 256u) {
+    for (uint32_t b = 0; b < n_all; b += 256u) {
         if (tid == 0) { s_nmed = 0; s_nlarge = 0; }
         __syncthreads();
         uint32_t e = b + tid;
-        if (e < n) {
-            uint32_t slot = fb.entries[off + e];
+        bool mine = e < n_all;
+        uint32_t slot = 0;
+        if (mine) {
+            slot = e < n ? fb.entries[off + e] : fb.wide_list[e - n];
             if (!guard(slot < cap.records, fb.counters, kGuardRaster)) slot = 0;
+            if (e >= n) {
+                const uint32_t tw = fb.tilewords[slot].x;
+                const uint32_t rx0 = tw & 255u, ry0 = (tw >> 8) & 255u;
+                mine = my_tx >= rx0 && my_tx <= rx0 + ((tw >> 16) & 255u) && my_ty >= ry0 && my_ty <= ry0 + (tw >> 24);
+            }
+        }
+        if (mine) {
             SetupRecord r = load_record(fb.records, slot);
             int32_t xmin = min(r.x0, min(r.x1, r.x2)), xmax = max(r.x0, max(r.x1, r.x2));
             int32_t ymin = min(r.y0, min(r.y1, r.y2)), ymax = max(r.y0, max(r.y1, r.y2));

@@ -255,7 +255,8 @@ private:
         uint32_t n = 0, tiles_x = 0, tiles_y = 0;
     };
     std::unordered_map<uint64_t, DetileList> detile_lists_;
-    Capacities cap_{0, 0, 0, 0};
+    Capacities cap_{0, 0, 0, 0, kWideListCap};
+    DeviceBuffer<uint32_t> d_wide_list_;
     uint32_t clip_records_ = 0;   // room in the record stream for the clipper's sub-triangles
 
     // pinned staging ring for the per-frame tables

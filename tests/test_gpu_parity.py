@@ -160,7 +160,7 @@ def test_rerender_after_changes_and_resize():
 
 def test_full_screen_triangles_many_tiles():
     # a few triangles far larger than the frame: every tile gets them (64-bit edge-function path)
-    w, h = 512, 320
+    w, h = 1024, 640      # 640 tiles: above the wide list's bar of 256
     s = SceneDesc("big", w, h, Camera(aspect_ratio=w / h), identity())
     pos = np.array([(-40, -30, 5), (40, -30, 5), (0, 50, 5), (-30, -30, 3), (30, -35, 9), (5, 45, 4)], dtype=np.float32)
     s.meshes.append(Mesh([Submesh(make_vertices(pos), np.arange(6, dtype=np.uint32))]))
@@ -168,8 +168,17 @@ def test_full_screen_triangles_many_tiles():
     s.lights.append((5, from_translation((0, 0, 2)), Light.point(10.0).with_color(Color(1, 1, 1, 2.0))))
     gpu, cpu = render_pair(s)
     assert_parity(gpu, cpu, min_covered=w * h)
+    # records that span the frame are not binned: they go on the wide list that every tile checks
     st = gpu.frame_stats()
-    assert st["n_bin_entries"] >= 2 * (w // 32) * (h // 32)
+    assert st["n_setup"] == 2 and st["n_bin_entries"] == 0
+    # the same triangles in a frame of which they cover a small part only: binned, 64-bit edges in the sweep
+    s2 = SceneDesc("big-far", w, h, Camera(aspect_ratio=w / h), identity())
+    s2.meshes.append(Mesh([Submesh(make_vertices(pos * np.array([0.02, 0.02, 1.0], np.float32)), np.arange(6, dtype=np.uint32))]))
+    s2.instances.append((1, identity(), 0))
+    s2.lights = list(s.lights)
+    gpu, cpu = render_pair(s2)
+    assert_parity(gpu, cpu, min_covered=2000)
+    assert gpu.frame_stats()["n_bin_entries"] > 4
 
 
 def test_tile_partition_union_equals_single():
