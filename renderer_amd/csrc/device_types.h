@@ -11,6 +11,8 @@ constexpr uint32_t kTilePixels = kTile * kTile;
 constexpr uint32_t kDirectPixels = 32;        // K2a rasterizes a triangle itself when its bbox holds at most this many pixel centres (RND_DIRECT_PIXELS, <= 64)
 constexpr uint32_t kWideListTiles = 256;      // a record touching more tiles than this AND an eighth of the frame's is not binned but put on the wide list (floors, walls, sky)
 constexpr uint32_t kWideListCap = 65536;
+constexpr uint32_t kRasterMaxSlices = 8;      // raster workgroups that may share one heavy tile (256 candidates per batch each)
+constexpr uint32_t kRasterExtraCap = 2048;    // work items (tile, slice >= 1) per pass
 constexpr uint32_t kOwnerGroup = 4;            // sort-first ownership: full-width stripes of this many tile rows, dealt round-robin
 constexpr int kSubpixelBits = 8;
 constexpr int kSub = 1 << kSubpixelBits;       // 256 sub-pixel steps per pixel
@@ -178,6 +180,8 @@ struct FrameCounters {
     uint32_t n_active;         // work units that survived k_cull
     uint32_t all_verts;        // a surviving unit uses a wide vertex range: transform every vertex block
     uint32_t n_wide;           // records on the wide list (not binned: every tile's raster workgroup checks them)
+    uint32_t n_extra;          // (tile, slice) work items of heavy tiles beyond their first raster workgroup
+    uint32_t pad[3];
 };
 
 struct Capacities {

@@ -29,6 +29,8 @@ struct FrameBuffers {
     float4* clip;                   // n_verts clip positions
     SnapVert* snap;                 // n_verts snapped positions + clip verdicts (K1 -> K2a)
     uint32_t* wide_list;            // record slots of the wide records of this pass
+    uint32_t* tile_slices;          // per tile: raster workgroups that share it (k_scan_tiles -> k_raster)
+    uint2* raster_extra;            // (tile, slice) of the workgroups beyond each tile's first
     uint32_t direct_pixels;         // K2a rasterizes triangles whose bbox holds at most this many pixel centres itself
     SetupRecord* records;
     uint2* tilewords;               // per record: .x = tx0 | ty0<<8 | (w-1)<<16 | (h-1)<<24, .y = position in its bin (single-tile records)

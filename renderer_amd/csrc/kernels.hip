@@ -894,6 +894,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(FrameBuffers fb, Capacities
     // statistics: triangles that survived setup (per-unit counts of k_setup; the clipper adds its own).
     // These loads are issued first so they overlap the scan's.
     const uint32_t n_active = min(fb.counters->n_active, fc.n_units);
+    const uint32_t n_wide = min(fb.counters->n_wide, cap.wide_list);
     uint32_t v = 0;
     for (uint32_t c0 = 0; c0 < n_active; c0 += 8u * 1024u) {
         uint32_t part[8];
@@ -923,6 +924,24 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(FrameBuffers fb, Capacities
         uint32_t cnt[kRun], sum = 0;
 #pragma unroll
         for (uint32_t k = 0; k < kRun; ++k) { const uint32_t local = tid * kRun + k; cnt[k] = s_tiles[local + local / 32u]; sum += cnt[k]; }
+        // heavy tiles (more than 256 candidates: bin entries + the wide list) are shared by several raster
+        // workgroups: the first is the tile's own, the others are work items (tile, slice) on a short list
+#pragma unroll
+        for (uint32_t k = 0; k < kRun; ++k) {
+            const uint32_t t = batch + tid * kRun + k;
+            if (t >= n_tiles) continue;
+            const uint32_t n_all = cnt[k] + n_wide;
+            uint32_t slices = 1;
+            if (n_all > 256u && owns_tile(t % fc.tiles_x, t / fc.tiles_x, fc.rank, fc.world)) {
+                const uint32_t want = min((n_all + 255u) / 256u, kRasterMaxSlices);
+                for (; slices < want; ++slices) {
+                    const uint32_t at = atomicAdd(&fb.counters->n_extra, 1u);
+                    if (at >= kRasterExtraCap) break;
+                    fb.raster_extra[at] = make_uint2(t, slices);
+                }
+                fb.tile_slices[t] = slices;     // (only read for tiles with more than 256 candidates)
+            }
+        }
         uint32_t inc = sum;
         for (int o = 1; o < 64; o <<= 1) {
             uint32_t up = __shfl_up(inc, o);
@@ -1084,7 +1103,17 @@ __global__ __launch_bounds__(256) void k_raster(FrameBuffers fb, Capacities cap)
 #endif
     constexpr uint32_t kMediumLanes = RND_MEDIUM_LANES;
     const uint32_t tid = threadIdx.x;
-    const uint32_t tile = fb.launch_order[blockIdx.x].tile;
+    // workgroups [0, n_owned) are the tiles' own; the ones behind them take the (tile, slice) work items
+    // k_scan_tiles listed for heavy tiles, whose candidates are dealt to the slices batch by batch
+    uint32_t tile, slice = 0;
+    if (blockIdx.x < fb.n_owned) tile = fb.launch_order[blockIdx.x].tile;
+    else {
+        const uint32_t at = blockIdx.x - fb.n_owned;
+        if (at >= min(fb.counters->n_extra, kRasterExtraCap)) return;
+        const uint2 item = fb.raster_extra[at];
+        tile = item.x; slice = item.y;
+        if (!guard(tile < fc.tiles_x * fc.tiles_y, fb.counters, kGuardRaster)) return;
+    }
     const int32_t tile_x0 = (int32_t)((tile % fc.tiles_x) * kTile), tile_y0 = (int32_t)((tile / fc.tiles_x) * kTile);
     const int32_t tile_x1 = min(tile_x0 + (int32_t)kTile, (int32_t)fc.width) - 1;
     const int32_t tile_y1 = min(tile_y0 + (int32_t)kTile, (int32_t)fc.height) - 1;
@@ -1094,11 +1123,14 @@ __global__ __launch_bounds__(256) void k_raster(FrameBuffers fb, Capacities cap)
     if (n == 0 && n_wide == 0) return;     // nothing binned here: the tile keeps what k_setup's direct path wrote
     const uint32_t my_tx = tile % fc.tiles_x, my_ty = tile / fc.tiles_x;
     const uint32_t n_all = n + n_wide;     // bin entries, then the wide list (filtered by its records' tile rects)
+    const uint32_t n_slices = slice == 0u && n_all <= 256u ? 1u : max(fb.tile_slices[tile], 1u);
+    if (slice * 256u >= n_all || slice >= n_slices) return;
+    const bool shared_tile = n_slices > 1u;  // several workgroups on this tile: they meet in the global words by atomic min
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(fb.vis) + (size_t)tile * kTilePixels;
-    for (uint32_t k = tid; k < kTilePixels; k += 256u) s_vis[k] = dst[k];
+    for (uint32_t k = tid; k < kTilePixels; k += 256u) s_vis[k] = slice == 0u ? dst[k] : kClearKey;
     const LdsSink sink{s_vis, tile_x0, tile_y0};
     __syncthreads();
-    for (uint32_t b = 0; b < n_all; b += 256u) {
+    for (uint32_t b = slice * 256u; b < n_all; b += n_slices * 256u) {
         if (tid == 0) { s_nmed = 0; s_nlarge = 0; }
         __syncthreads();
         uint32_t e = b + tid;
@@ -1169,7 +1201,14 @@ __global__ __launch_bounds__(256) void k_raster(FrameBuffers fb, Capacities cap)
         }
         __syncthreads();
     }
-    for (uint32_t k = tid; k < kTilePixels; k += 256u) dst[k] = s_vis[k];
+    if (!shared_tile) {
+        for (uint32_t k = tid; k < kTilePixels; k += 256u) dst[k] = s_vis[k];
+    } else {
+        for (uint32_t k = tid; k < kTilePixels; k += 256u) {
+            const unsigned long long v = s_vis[k];
+            if (v != kClearKey) __hip_atomic_fetch_min(&dst[k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1982,8 +2021,8 @@ void launch_bin(const FrameBuffers& fb, const FrameConst& fc, const Capacities& 
 }
 void launch_raster(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {
     if (!fb.n_owned) return;
-    if (fb.alpha_test) hipLaunchKernelGGL(k_raster<true>, dim3(fb.n_owned), dim3(256), 0, stream, fb, cap);
-    else hipLaunchKernelGGL(k_raster<false>, dim3(fb.n_owned), dim3(256), 0, stream, fb, cap);
+    if (fb.alpha_test) hipLaunchKernelGGL(k_raster<true>, dim3(fb.n_owned + kRasterExtraCap), dim3(256), 0, stream, fb, cap);
+    else hipLaunchKernelGGL(k_raster<false>, dim3(fb.n_owned + kRasterExtraCap), dim3(256), 0, stream, fb, cap);
 }
 void launch_shade(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream) {
     if (!fb.n_owned) return;

@@ -96,7 +96,7 @@ VisualServer::~VisualServer() {
     for (auto& kv : meshes_)
         for (auto& s : kv.second.submeshes) { s.vertex_buffer.release(); s.positions.release(); s.index_buffer.release(); s.chunks.release(); }
     for (int k = 0; k < 2; ++k) { d_tables_[k].release(); d_clip_[k].release(); d_vis_[k].release(); d_counters_[k].release(); }
-    d_snap_.release(); d_wide_list_.release();
+    d_snap_.release(); d_wide_list_.release(); d_tile_slices_.release(); d_raster_extra_.release();
     d_records_.release(); d_tilewords_.release(); d_clip_queue_.release(); d_chunk_count_.release(); d_vblock_needed_.release(); d_active_units_.release(); d_tile_count_.release();
     d_tile_offset_.release(); d_tile_cursor_.release(); d_entries_.release();
     for (auto& kv : textures_) kv.second.texels.release();
@@ -633,6 +633,8 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     d_vblock_needed_.ensure((size_t)fc.n_verts / kVertexBlock + 2);
     d_entries_.ensure(cap_.entries);
     d_wide_list_.ensure(cap_.wide_list);
+    d_tile_slices_.ensure(std::max<size_t>(n_tiles, n_sets ? kShadowTiles : 0));
+    d_raster_extra_.ensure(kRasterExtraCap);
     if (world_ > 1) d_tiles_.ensure(std::max<size_t>((size_t)n_owned_ * kTilePixels * 4, 4));
     if (want_packed_) d_packed_.ensure((size_t)width_ * height_);
     if (want_hdr) d_hdr_.ensure((size_t)width_ * height_ * 3);
@@ -715,7 +717,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     fb.chunk_count = d_chunk_count_.ptr;
     fb.unit_bases = reinterpret_cast<const uint32_t*>(tb + off_ub); fb.active_units = reinterpret_cast<uint2*>(d_active_units_.ptr); fb.vblock_needed = d_vblock_needed_.ptr;
     fb.tile_count = d_tile_count_.ptr; fb.tile_offset = d_tile_offset_.ptr; fb.tile_cursor = d_tile_cursor_.ptr;
-    fb.wide_list = d_wide_list_.ptr;
+    fb.wide_list = d_wide_list_.ptr; fb.tile_slices = d_tile_slices_.ptr; fb.raster_extra = d_raster_extra_.ptr;
     fb.entries = d_entries_.ptr; fb.counters = d_counters_[p].ptr;
     fb.launch_order = d_launch_order_.ptr; fb.n_owned = n_owned_;
     fb.vis = d_vis_[p].ptr;

@@ -256,7 +256,8 @@ private:
     };
     std::unordered_map<uint64_t, DetileList> detile_lists_;
     Capacities cap_{0, 0, 0, 0, kWideListCap};
-    DeviceBuffer<uint32_t> d_wide_list_;
+    DeviceBuffer<uint32_t> d_wide_list_, d_tile_slices_;
+    DeviceBuffer<uint2> d_raster_extra_;
     uint32_t clip_records_ = 0;   // room in the record stream for the clipper's sub-triangles
 
     // pinned staging ring for the per-frame tables

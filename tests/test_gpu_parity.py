@@ -576,3 +576,22 @@ def test_pipelined_frames_last_frame_wins():
     alone.render()
     assert (alone.read_triangle_ids() == ids).all() and (alone.read_depth().view(np.uint32) == depth.view(np.uint32)).all()
     assert (alone.read_color_rgba8() == img).all()
+
+
+def test_heavy_tiles_shared_by_several_raster_workgroups():
+    """More than 256 candidates per tile: k_scan_tiles hands the tile to up to eight raster workgroups that
+    meet by atomic min; with far more heavy tiles than work items (2048 per pass) some tiles get fewer
+    workgroups than they ask for.  Both must give the single-workgroup result (the oracle's)."""
+    s = soup_scene(55, 256, 160, n_meshes=5, n_tri=500, size=2.0, lights=2)
+    s.lights = [l for l in s.lights if l[2].kind_id() == 1]
+    gpu, cpu = render_pair(s)
+    assert_parity(gpu, cpu, min_covered=int(0.9 * 256 * 160))
+    st = gpu.frame_stats()
+    assert st["n_bin_entries"] > 300 * st["n_tiles"]          # every tile is heavy
+    s = soup_scene(56, 1600, 1200, n_meshes=4, n_tri=400, size=1.5, lights=2)       # ~1900 tiles, most of them heavy
+    s.lights = [l for l in s.lights if l[2].kind_id() == 1]
+    gpu, cpu = render_pair(s)
+    assert_parity(gpu, cpu, min_covered=int(0.5 * 1600 * 1200))
+    # (here most records span more than an eighth of the frame: they reach the tiles through the wide list,
+    # which makes every one of the 1900 tiles heavy)
+    assert gpu.frame_stats()["n_setup"] > 600
