@@ -251,6 +251,10 @@ void VisualServer::register_mesh(uint32_t mesh_id, uint32_t n_submeshes, const r
                 }
             }
             infos[c] = ci;
+            for (int a = 0; a < 3; ++a) {
+                if (c == 0) { s.box_lo[a] = ci.lo[a]; s.box_hi[a] = ci.hi[a]; }
+                else { s.box_lo[a] = std::min(s.box_lo[a], ci.lo[a]); s.box_hi[a] = std::max(s.box_hi[a], ci.hi[a]); }
+            }
         }
         s.chunks.ensure(std::max<size_t>(s.n_chunks, 1));
         if (s.n_chunks) HIP_CHECK(hipMemcpy(s.chunks.ptr, infos.data(), infos.size() * sizeof(ChunkInfo), hipMemcpyHostToDevice));
@@ -548,6 +552,52 @@ void VisualServer::build_frame(std::vector<DrawItem>& items, std::vector<uint32_
     if (msaa_ > 1) sample_shift(0, fc.sub_dx, fc.sub_dy);
 }
 
+// Whether any shadow-casting instance can reach a cascade's clip volume: the bounds of each submesh
+// through the instance's transform and the cascade matrix, rejected when all eight corners lie outside
+// one plane by a relative margin (the test k_cull applies per chunk, in double here).  A submesh the
+// test rejects has every triangle outside the volume, so leaving the pass out draws exactly what
+// running it would: nothing.  Scenes with many instances are not examined (the answer is "yes").
+bool VisualServer::cascade_has_casters(const Mat4& cascade) const {
+    if (mesh_instances_.size() > 32) return true;      // (the test costs the host ~1 us per instance and pass)
+    for (const RenderMeshInstance& inst : mesh_instances_) {
+        if (!inst.casts_shadows) continue;
+        const RenderMesh& mesh = meshes_.at(inst.mesh);
+        for (const RenderSubmesh& sub : mesh.submeshes) {
+            if (!sub.index_count) continue;
+            bool out[6] = {true, true, true, true, true, true};
+            bool usable = true;
+            for (int c = 0; c < 8 && usable; ++c) {
+                const double p[3] = {(c & 1) ? sub.box_hi[0] : sub.box_lo[0], (c & 2) ? sub.box_hi[1] : sub.box_lo[1], (c & 4) ? sub.box_hi[2] : sub.box_lo[2]};
+                double w4[4], q[4];
+                for (int r = 0; r < 4; ++r) {
+                    const Vec4* col = inst.transform.col;
+                    const double cr[4] = {r == 0 ? col[0].x : r == 1 ? col[0].y : r == 2 ? col[0].z : col[0].w,
+                                          r == 0 ? col[1].x : r == 1 ? col[1].y : r == 2 ? col[1].z : col[1].w,
+                                          r == 0 ? col[2].x : r == 1 ? col[2].y : r == 2 ? col[2].z : col[2].w,
+                                          r == 0 ? col[3].x : r == 1 ? col[3].y : r == 2 ? col[3].z : col[3].w};
+                    w4[r] = cr[0] * p[0] + cr[1] * p[1] + cr[2] * p[2] + cr[3];
+                }
+                for (int r = 0; r < 4; ++r) {
+                    const Vec4* col = cascade.col;
+                    const double cr[4] = {r == 0 ? col[0].x : r == 1 ? col[0].y : r == 2 ? col[0].z : col[0].w,
+                                          r == 0 ? col[1].x : r == 1 ? col[1].y : r == 2 ? col[1].z : col[1].w,
+                                          r == 0 ? col[2].x : r == 1 ? col[2].y : r == 2 ? col[2].z : col[2].w,
+                                          r == 0 ? col[3].x : r == 1 ? col[3].y : r == 2 ? col[3].z : col[3].w};
+                    q[r] = cr[0] * w4[0] + cr[1] * w4[1] + cr[2] * w4[2] + cr[3] * w4[3];
+                }
+                if (!(std::isfinite(q[0]) && std::isfinite(q[1]) && std::isfinite(q[2]) && std::isfinite(q[3]))) { usable = false; break; }
+                const double e = 1.0e-3 * (std::fabs(q[0]) + std::fabs(q[1]) + std::fabs(q[2]) + std::fabs(q[3])) + 1.0e-30;
+                out[0] = out[0] && (q[0] + q[3] < -e); out[1] = out[1] && (q[3] - q[0] < -e);
+                out[2] = out[2] && (q[1] + q[3] < -e); out[3] = out[3] && (q[3] - q[1] < -e);
+                out[4] = out[4] && (q[2] < -e);        out[5] = out[5] && (q[3] - q[2] < -e);
+            }
+            if (!usable) return true;
+            if (!(out[0] || out[1] || out[2] || out[3] || out[4] || out[5])) return true;
+        }
+    }
+    return false;
+}
+
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // The standard 4x sample pattern, offsets from the pixel corner in 1/16 px; the shift that puts sample
@@ -590,6 +640,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     std::vector<ShadowSet> sets(n_sets);
     if (n_sets) {
         if (shadow_layers_[p].size() < n_sets) shadow_layers_[p].resize(n_sets);
+        if (shadow_layer_clear_[p].size() < n_sets) shadow_layer_clear_[p].resize(n_sets, std::array<bool, 4>{false, false, false, false});
         for (uint32_t k = 0; k < n_sets; ++k) {
             shadow_layers_[p][k].ensure((size_t)kShadowCascades * kShadowTiles * kTilePixels);
             const RenderLight& rl = lights_[shadowed[k]];
@@ -763,6 +814,10 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     mark(7, gs);
     for (uint32_t k = 0; k < n_sets; ++k)
         for (uint32_t c = 0; c < kShadowCascades; ++c) {
+            // a cascade no caster can reach stays cleared: its eight launch-bound kernels (and a 33 MB clear) are
+            // most of a small scene's frame (C1': three of the four cascades)
+            const bool casters = cascade_has_casters(lights_[shadowed[k]].cascades[c]);
+            if (!casters && shadow_layer_clear_[p][k][c]) continue;
             FrameBuffers sfb = fb;
             sfb.items = reinterpret_cast<const DrawItem*>(tb + off_si); sfb.lights = nullptr; sfb.shadow_sets = nullptr; sfb.alpha_test = 0;
             sfb.counters = d_counters_[p].ptr + 1 + k * kShadowCascades + c;
@@ -772,6 +827,8 @@ void VisualServer::enqueue_frame(bool want_hdr) {
             const FrameConst& sfc = consts[1 + k * kShadowCascades + c];
             sfb.frame_const = const_slot(1 + k * kShadowCascades + c);
             clear(sfb, sfc);
+            shadow_layer_clear_[p][k][c] = !casters;
+            if (!casters) continue;
             launch_cull(sfb, sfc, gs);
             launch_transform(sfb, sfc, gs);
             launch_setup(sfb, sfc, cap_, gs);
@@ -849,7 +906,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     // the replay costs the host as much as the launches (25.7 vs 30.1 us of 61 us per frame) and the
     // frame rate does not move, so the plain launches stay the default.
     bool launched = false;
-    if (use_graphs_ && !timed && !overlay && !overlap) {
+    if (use_graphs_ && !timed && !overlay && !overlap && !n_sets) {
         std::vector<uint8_t> key;
         auto add = [&](const void* p, size_t n) { const uint8_t* b = static_cast<const uint8_t*>(p); key.insert(key.end(), b, b + n); };
         add(&fb, sizeof fb); add(&cap_, sizeof cap_);

@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -57,6 +58,7 @@ struct RenderSubmesh {           // visual_server.rs:948-953
     uint32_t n_chunks = 0;
     uint32_t index_count = 0, vertex_count = 0;
     uint32_t material = RND_NONE;
+    float box_lo[3] = {0, 0, 0}, box_hi[3] = {0, 0, 0};   // object-space bounds (infinite on an axis with a non-finite coordinate)
 };
 struct RenderMesh { std::vector<RenderSubmesh> submeshes; };
 struct RenderTexture {           // RenderScene::textures (visual_server.rs:901) as decoded RGBA f32 levels
@@ -244,6 +246,8 @@ private:
     uint32_t n_counter_sets_ = 1, h_counter_sets_ = 0;
     // shadow cascades of the directional lights
     DeviceBuffer<TileRef> d_shadow_order_;
+    std::vector<std::array<bool, 4>> shadow_layer_clear_[2];     // the layer holds nothing but the clear value (a cascade without casters is not rendered again)
+    bool cascade_has_casters(const Mat4& cascade) const;
     std::vector<DeviceBuffer<uint64_t>> shadow_layers_[2];   // per frame parity and shadowed light: kShadowCascades visibility buffers
     DeviceBuffer<TileRef> d_launch_order_;
     DeviceBuffer<uint64_t> d_vis_[2];

@@ -595,3 +595,24 @@ def test_heavy_tiles_shared_by_several_raster_workgroups():
     # (here most records span more than an eighth of the frame: they reach the tiles through the wide list,
     # which makes every one of the 1900 tiles heavy)
     assert gpu.frame_stats()["n_setup"] > 600
+
+
+def test_cascades_without_casters_are_skipped_and_come_back():
+    """A cascade no shadow caster can reach is not rendered (its layer stays cleared).  The caster moves
+    through the cascades' depth ranges over consecutive frames of ONE context - layers must be drawn when
+    it arrives and cleared again when it leaves - and every frame must equal the oracle's."""
+    s = shadow_scene()
+    gpu = VisualServer(s.width, s.height, device=0)
+    handles = s.populate(gpu)
+    for step, dz in enumerate([0.0, 0.0, 9.0, 22.0, 60.0, 0.0, 0.0]):
+        plate = from_translation((0, 0.2, 3 + dz)) @ from_rotation_x(math.pi / 2) @ from_scale((1.6, 1.6, 1))
+        floor = from_translation((0, -1, 3 + dz)) @ from_rotation_x(math.pi / 2) @ from_scale((9, 9, 1))
+        gpu.set_mesh_instance(1, floor, handles[0])
+        gpu.set_mesh_instance(2, plate, handles[0])
+        gpu.render()
+        cpu = oracle_server(s.width, s.height)
+        h2 = s.populate(cpu)
+        cpu.set_mesh_instance(1, floor, h2[0])
+        cpu.set_mesh_instance(2, plate, h2[0])
+        cpu.render()
+        assert_parity(gpu, cpu, min_covered=20, shadow_taps=True)
