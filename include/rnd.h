@@ -259,7 +259,11 @@ int rnd_detile_gathered(rnd_ctx* ctx, uint32_t world, const void* dev_gathered, 
 int rnd_packed_device_ptr(rnd_ctx* ctx, void** dev_ptr, uint64_t* n_bytes);
 /* Unpack a (reduced) packed frame on this context's device into its RGBA8 + depth frame. */
 int rnd_unpack(rnd_ctx* ctx, const void* dev_packed);
-/* Use the caller's HIP stream (hipStream_t as void*) for all work of this context; NULL = own stream. */
+/* Use the caller's HIP stream (hipStream_t as void*) for this context; NULL = own stream.  Shading, present,
+ * the 2D overlay, read-backs, detile/unpack and everything the caller enqueues behind rnd_render are ordered
+ * on this stream.  The geometry phase of a frame runs on an internal stream that this one waits for through
+ * an event (so that it overlaps the previous frame's shading); with the environment variable
+ * RND_OVERLAP=0 every kernel is launched on this stream, which is what a caller needs who captures it. */
 int rnd_set_stream(rnd_ctx* ctx, void* hip_stream);
 /* Device pointer of the row-major RGBA8 frame (for callers that keep the image on the GPU). */
 int rnd_color_device_ptr(rnd_ctx* ctx, void** dev_ptr, uint64_t* n_bytes);
