@@ -138,3 +138,38 @@ def test_overlapped_frames_keep_their_own_output():
         assert torch.equal(one, bufs[k]), f"frame {k} differs from the same frame rendered alone"
         distinct.add(int(one.to(torch.int64).sum().item()))
     assert len(distinct) >= 6          # the frames really differ from each other
+
+
+@pytest.mark.parametrize("env", [{"RND_OVERLAP": "0"}, {"RND_GRAPH": "1"}])
+def test_single_stream_and_graph_modes(env):
+    """The two launch modes chosen by environment variables at context creation (everything on the
+    caller's stream; the frame's kernel sequence replayed as a HIP graph) render the same frames as the
+    default mode: a child process renders a run of frames in that mode and checks them against the oracle."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np
+from renderer_amd import VisualServer
+from renderer_amd.types import from_translation
+from tests.helpers import oracle_server
+from tests.test_gpu_parity import soup_scene
+s = soup_scene(17, 224, 160, n_meshes=3, n_tri=80, lights=3)
+s.lights = [l for l in s.lights if l[2].kind_id() == 1]
+gpu, cpu = VisualServer(s.width, s.height, device=0), oracle_server(s.width, s.height)
+s.populate(gpu); s.populate(cpu)
+for k in range(12):
+    cam = from_translation((0.1 * (k % 3), 0.0, -1.0 - 0.05 * k))
+    gpu.set_camera(cam, s.camera)
+    gpu.render()
+cpu.set_camera(cam, s.camera)
+cpu.render()
+assert (gpu.read_triangle_ids() == cpu.read_triangle_ids()).all()
+assert (gpu.read_depth().view(np.uint32) == cpu.read_depth().view(np.uint32)).all()
+assert np.abs(gpu.read_color_rgba8().astype(int) - cpu.read_color_rgba8().astype(int)).max() <= 1
+print("mode ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env={**os.environ, **env, "PYTHONPATH": root},
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "mode ok" in out.stdout, (out.stdout[-500:], out.stderr[-1500:])
