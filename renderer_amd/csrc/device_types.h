@@ -20,7 +20,11 @@ constexpr float kGuardBand = 16.0f;            // guard band half-extent in NDC 
 constexpr uint32_t kMaxRenderSize = 8192;      // tile coordinates are packed in 8 bits
 constexpr uint64_t kClearKey = (uint64_t(0x3F800000u) << 32) | 0xFFFFFFFFull;   // depth 1.0, no triangle
 constexpr uint32_t kMaxLights = 256;
-constexpr uint32_t kChunkTris = 1024;          // triangles per setup work unit (one workgroup)
+constexpr uint32_t kChunkTris = 1024;          // triangles per setup work unit (one workgroup) in large frames
+constexpr uint32_t kChunkTrisSmall = 256;      // ... in frames of at most kSmallFrameTris triangles: four times the workgroups,
+                                               // one pass each (C1' 4150 -> 5660 frames/s, C2 9300 -> 10000; at C3's 10 M
+                                               // triangles the 30 k extra units cost the cull/scan/bin kernels 4 %, C5 18 %)
+constexpr uint32_t kSmallFrameTris = 2u << 20;
 constexpr uint32_t kVertexBlock = 256;         // vertices per transform workgroup
 constexpr uint32_t kShadowSize = 2048;         // shadow map edge (visual_server.rs:366-367)
 constexpr uint32_t kShadowCascades = 4;        // settings.shadow_cascades (visual_server.rs:88)
@@ -34,7 +38,7 @@ enum : uint32_t {
     kItemAlphaTest = 32u,           // the texture has alpha below 1: base.a < 0.5 is decided per fragment
 };
 
-// A run of kChunkTris consecutive triangles of a submesh, described once at registration: the
+// A run of kChunkTris (or kChunkTrisSmall) consecutive triangles of a submesh, described once at registration: the
 // object-space box of its vertices and the range of vertex indices it uses.  Per frame the box is
 // projected to decide whether the chunk can touch the view volume and the screen stripes this
 // context owns (k_cull); chunks that cannot are never set up, and vertex blocks no surviving chunk
@@ -113,6 +117,7 @@ struct FrameConst {
     uint32_t n_tris, n_verts;
     uint32_t rank, world;
     uint32_t n_units;              // setup work units of the frame (chunks over all draw items)
+    uint32_t chunk_tris;           // triangles per work unit this frame: kChunkTris or kChunkTrisSmall
     uint32_t n_samples;            // 1, or 4 (MSAA): visibility planes of the frame
     int32_t sub_dx, sub_dy;        // whole sub-pixel steps added to every snapped vertex: the sample this
                                    // geometry pass resolves, moved onto the pixel centre (0 without MSAA)

@@ -667,11 +667,10 @@ __device__ __forceinline__ void direct_pixel(const DirectTri& d, uint32_t k, con
 // A triangle whose bbox holds at most fb.direct_pixels pixel centres (kDirectPixels; the bulk at C2..C5 density) is
 // rasterized right here by its lane, straight into the visibility buffer (GlobalSink); only the
 // larger ones become records and go through the bins to the per-tile raster kernel.
-// Slots of the record stream are deterministic: workgroup b owns slots [b*kSetupChunk,
-// (b+1)*kSetupChunk), fills them densely from the front with a ballot + LDS prefix over its
+// Slots of the record stream are deterministic: workgroup b owns slots [b*chunk_tris,
+// (b+1)*chunk_tris) (FrameConst::chunk_tris, a multiple of 256), fills them densely from the front with a ballot + LDS prefix over its
 // waves and leaves the number it used in chunk_count[b].  No global counter sits on this path (one
 // word takes ~88 atomics/us on MI355X: 10M triangles / 64 lanes on one counter cost 1.4 ms here).
-constexpr uint32_t kSetupChunk = kChunkTris;
 
 // One workgroup per surviving work unit (draw item, chunk of kChunkTris triangles): the item is
 // uniform for the whole workgroup, so its fields come in through scalar loads.
@@ -691,18 +690,19 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
     __syncthreads();
     typedef const __attribute__((address_space(4))) DrawItem* cptr_item;
     cptr_item d = (cptr_item)fb.items + item_s;
-    const uint32_t first_t = chunk_s * kSetupChunk;                        // first triangle of the chunk within its item
+    const uint32_t chunk_tris = fc.chunk_tris;
+    const uint32_t first_t = chunk_s * chunk_tris;                         // first triangle of the chunk within its item
     const uint32_t item_tris = d->n_tris;
-    const uint32_t n_here = item_tris > first_t ? min(item_tris - first_t, kSetupChunk) : 0u;
+    const uint32_t n_here = item_tris > first_t ? min(item_tris - first_t, chunk_tris) : 0u;
     const uint32_t vb = d->vert_base, nv = d->n_verts, tri_base = d->tri_base;
     const bool alpha_item = (d->flags & kItemAlphaTest) != 0u;       // fragments take the texture alpha test
     gptr_u32 indices = (gptr_u32)d->indices;
     const bool tables_ok = guard(vb + nv <= fc.n_verts, fb.counters, kGuardSetup);
-    const uint32_t chunk_base = blockIdx.x * kSetupChunk;
+    const uint32_t chunk_base = blockIdx.x * chunk_tris;
     const uint32_t n_tiles = fc.tiles_x * fc.tiles_y;
     const GlobalSink direct_sink{reinterpret_cast<unsigned long long*>(fb.vis), fc.tiles_x, fc.rank, fc.world};
     uint32_t valid = 0;
-    for (uint32_t iter = 0; iter < kSetupChunk / 256u; ++iter) {
+    for (uint32_t iter = 0; iter < chunk_tris / 256u; ++iter) {
         const uint32_t local = iter * 256u + threadIdx.x;
         const uint32_t gid = tri_base + first_t + local;                   // draw-order triangle id
         bool emit = false, need_clip = false;
@@ -1009,8 +1009,8 @@ __global__ __launch_bounds__(256) void k_bin_fill(FrameBuffers fb, Capacities ca
     const uint32_t n_chunks = fc.n_units;
     if (blockIdx.x < n_chunks) {
         if (blockIdx.x >= fb.counters->n_active) return;
-        const uint32_t base = blockIdx.x * kSetupChunk;
-        const uint32_t n = min(fb.chunk_count[blockIdx.x], kSetupChunk);
+        const uint32_t base = blockIdx.x * fc.chunk_tris;
+        const uint32_t n = min(fb.chunk_count[blockIdx.x], fc.chunk_tris);
         for (uint32_t k0 = 0; k0 < n; k0 += 256u) bin_record(fb, fc, cap, k0 + threadIdx.x < n, base + k0 + threadIdx.x);
     } else {
         const uint32_t n = min(cap.setup_slots + fb.counters->n_records, cap.records);

@@ -232,15 +232,19 @@ void VisualServer::register_mesh(uint32_t mesh_id, uint32_t n_submeshes, const r
                                s.positions.ptr + 2 * (size_t)d.n_vertices, stream_);
         // per-chunk object-space boxes and vertex ranges for the per-frame work-unit culling
         const uint32_t n_tris = d.n_indices / 3;
+        // (both chunkings: the small chunks first, then the large ones, each the union of four small)
+        s.n_chunks_small = (n_tris + kChunkTrisSmall - 1) / kChunkTrisSmall;
         s.n_chunks = (n_tris + kChunkTris - 1) / kChunkTris;
-        std::vector<ChunkInfo> infos(s.n_chunks);
+        static_assert(kChunkTris % kChunkTrisSmall == 0 && kChunkTrisSmall % 256 == 0, "chunk sizes");
+        constexpr uint32_t kPerLarge = kChunkTris / kChunkTrisSmall;
+        std::vector<ChunkInfo> infos(s.n_chunks_small + s.n_chunks);
         const float inf = std::numeric_limits<float>::infinity();
-        for (uint32_t c = 0; c < s.n_chunks; ++c) {
+        for (uint32_t c = 0; c < s.n_chunks_small; ++c) {
             ChunkInfo ci;
             for (int a = 0; a < 3; ++a) { ci.lo[a] = inf; ci.hi[a] = -inf; }
             ci.vmin = 0xFFFFFFFFu; ci.vmax = 0;
-            const size_t i_end = std::min<size_t>((size_t)(c + 1) * kChunkTris * 3, d.n_indices);
-            for (size_t i = (size_t)c * kChunkTris * 3; i < i_end; ++i) {
+            const size_t i_end = std::min<size_t>((size_t)(c + 1) * kChunkTrisSmall * 3, d.n_indices);
+            for (size_t i = (size_t)c * kChunkTrisSmall * 3; i < i_end; ++i) {
                 const uint32_t v = d.indices[i];
                 ci.vmin = std::min(ci.vmin, v); ci.vmax = std::max(ci.vmax, v);
                 const float* p = d.vertices[v].position;
@@ -251,13 +255,19 @@ void VisualServer::register_mesh(uint32_t mesh_id, uint32_t n_submeshes, const r
                 }
             }
             infos[c] = ci;
+            ChunkInfo& big = infos[s.n_chunks_small + c / kPerLarge];
+            if (c % kPerLarge == 0) big = ci;
+            else {
+                big.vmin = std::min(big.vmin, ci.vmin); big.vmax = std::max(big.vmax, ci.vmax);
+                for (int a = 0; a < 3; ++a) { big.lo[a] = std::min(big.lo[a], ci.lo[a]); big.hi[a] = std::max(big.hi[a], ci.hi[a]); }
+            }
             for (int a = 0; a < 3; ++a) {
                 if (c == 0) { s.box_lo[a] = ci.lo[a]; s.box_hi[a] = ci.hi[a]; }
                 else { s.box_lo[a] = std::min(s.box_lo[a], ci.lo[a]); s.box_hi[a] = std::max(s.box_hi[a], ci.hi[a]); }
             }
         }
-        s.chunks.ensure(std::max<size_t>(s.n_chunks, 1));
-        if (s.n_chunks) HIP_CHECK(hipMemcpy(s.chunks.ptr, infos.data(), infos.size() * sizeof(ChunkInfo), hipMemcpyHostToDevice));
+        s.chunks.ensure(std::max<size_t>(infos.size(), 1));
+        if (!infos.empty()) HIP_CHECK(hipMemcpy(s.chunks.ptr, infos.data(), infos.size() * sizeof(ChunkInfo), hipMemcpyHostToDevice));
         mesh.submeshes.push_back(s);
     }
     HIP_CHECK(hipStreamSynchronize(stream_));   // the caller may free its arrays on return
@@ -502,12 +512,13 @@ void VisualServer::build_frame(std::vector<DrawItem>& items, std::vector<uint32_
                 frame_textured_ = true;
                 if (!tex->second.opaque && !(d.flags & kItemSkip)) { d.flags |= kItemAlphaTest; frame_alpha_test_ = true; }
             }
-            d.chunks = s.chunks.ptr; d.n_chunks = s.n_chunks; d.unit_base = (uint32_t)unit_base;
+            // small chunks until the frame turns out to be a large one (patched below)
+            d.chunks = s.chunks.ptr; d.n_chunks = s.n_chunks_small; d.unit_base = (uint32_t)unit_base;
             vert_bases.push_back(d.vert_base);
             tri_bases.push_back(d.tri_base);
             unit_bases.push_back(d.unit_base);
             vert_base += d.n_verts; tri_base += d.n_tris; unit_base += d.n_chunks;
-            if (vert_base >= 0xFFFFFFFFull || tri_base >= 0xFFFFFFFFull || unit_base * kChunkTris >= 0xFFFFFFF0ull) throw Error(RND_ERR_INVALID, "frame exceeds 2^32 vertices or triangles");
+            if (vert_base >= 0xFFFFFFFFull || tri_base >= 0xFFFFFFFFull || unit_base * kChunkTrisSmall >= 0xFFFFFFF0ull) throw Error(RND_ERR_INVALID, "frame exceeds 2^32 vertices or triangles");
             items.push_back(d);
             // the same geometry as the shadow passes draw it (render_shadow_map.wgsl:25-33: model matrix
             // only, no billboard modes; pipeline3d.rs:268-313: no fragment stage, so no alpha test;
@@ -522,6 +533,21 @@ void VisualServer::build_frame(std::vector<DrawItem>& items, std::vector<uint32_
     }
     vert_bases.push_back((uint32_t)vert_base);
     tri_bases.push_back((uint32_t)tri_base);
+    fc_.chunk_tris = kChunkTrisSmall;
+    if (tri_base > kSmallFrameTris) {
+        // a large frame: the large chunks of every submesh (they follow the small ones in its table)
+        fc_.chunk_tris = kChunkTris;
+        unit_base = 0;
+        for (size_t k = 0; k < items.size(); ++k) {
+            DrawItem& d = items[k];
+            d.chunks += d.n_chunks;
+            d.n_chunks = (d.n_tris + kChunkTris - 1) / kChunkTris;
+            d.unit_base = unit_bases[k] = (uint32_t)unit_base;
+            if (any_directional) { DrawItem& sd = shadow_items[k]; sd.chunks = d.chunks; sd.n_chunks = d.n_chunks; sd.unit_base = d.unit_base; }
+            unit_base += d.n_chunks;
+        }
+        if (unit_base * kChunkTris >= 0xFFFFFFF0ull) throw Error(RND_ERR_INVALID, "frame exceeds 2^32 record slots");
+    }
     unit_bases.push_back((uint32_t)unit_base);
     fc_.n_units = (uint32_t)unit_base;
     for (const RenderLight& l : lights_) {
@@ -669,7 +695,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     const size_t n_tiles = (size_t)tiles_x_ * tiles_y_;
 
     // capacities
-    cap_.setup_slots = fc.n_units * kChunkTris;
+    cap_.setup_slots = fc.n_units * fc.chunk_tris;
     clip_records_ = std::max<uint32_t>(clip_records_, fc.n_tris / 8 + 4096);
     cap_.records = (uint32_t)std::min<uint64_t>((uint64_t)cap_.setup_slots + clip_records_, 0xFFFFFFF0ull);
     if (cap_.clip_queue < std::max<uint32_t>(fc.n_tris / 8, 65536)) cap_.clip_queue = std::max<uint32_t>(fc.n_tris / 8, 65536);

@@ -54,8 +54,8 @@ struct RenderSubmesh {           // visual_server.rs:948-953
     DeviceBuffer<rnd_vertex> vertex_buffer;
     DeviceBuffer<float> positions;       // px | py | pz, n_verts each
     DeviceBuffer<uint32_t> index_buffer;
-    DeviceBuffer<ChunkInfo> chunks;      // one per kChunkTris triangles
-    uint32_t n_chunks = 0;
+    DeviceBuffer<ChunkInfo> chunks;      // one per kChunkTrisSmall triangles, then one per kChunkTris triangles
+    uint32_t n_chunks = 0, n_chunks_small = 0;
     uint32_t index_count = 0, vertex_count = 0;
     uint32_t material = RND_NONE;
     float box_lo[3] = {0, 0, 0}, box_hi[3] = {0, 0, 0};   // object-space bounds (infinite on an axis with a non-finite coordinate)

@@ -616,3 +616,29 @@ def test_cascades_without_casters_are_skipped_and_come_back():
         cpu.set_mesh_instance(2, plate, h2[0])
         cpu.render()
         assert_parity(gpu, cpu, min_covered=20, shadow_taps=True)
+
+
+def test_frame_crosses_the_work_unit_size_threshold():
+    """Frames of up to 2 Mi triangles are cut into 256-triangle setup work units, larger ones into
+    1024-triangle units (kSmallFrameTris): the same scene below, above and below the threshold again."""
+    s = c2_grid_1m(width=320, height=180, scale=1.05)
+    n_tris = sum(len(sub.indices) // 3 for sub in s.meshes[0].submeshes)
+    assert len(s.meshes) == 1 and len(s.instances) == 1 and (1 << 20) < n_tris < (2 << 20)
+    gpu, cpu = VisualServer(s.width, s.height, device=0), oracle_server(s.width, s.height)
+    handles = {}
+    for vs in (gpu, cpu):
+        handles[vs] = s.populate(vs)
+    second = from_translation((0.3, -0.2, 0.4)) @ from_rotation_y(0.05)
+    for copies in (1, 2, 1):
+        for vs in (gpu, cpu):
+            vs.reset_scene()                 # instances and lights go, registered meshes stay
+            vs.set_camera(s.camera_transform, s.camera)
+            for lid, t, light in s.lights:
+                vs.set_light(lid, t, light)
+            nid, t, m = s.instances[0]
+            vs.set_mesh_instance(nid, t, handles[vs][m])
+            if copies == 2:
+                vs.set_mesh_instance(7001, second, handles[vs][m])
+            vs.render()
+        assert gpu.frame_stats()["n_triangles"] == copies * n_tris
+        assert_parity(gpu, cpu, min_covered=320 * 180 // 2)
