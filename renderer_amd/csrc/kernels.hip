@@ -1315,8 +1315,13 @@ __device__ __forceinline__ void prepare_pixel(const DrawItem& d, FrameConstRef f
     vb.position[0] = b0v.x; vb.position[1] = b0v.y; vb.position[2] = b0v.z; vb.normal[0] = b0v.w; vb.normal[1] = b1v.x; vb.normal[2] = b1v.y;
     vc.position[0] = c0v.x; vc.position[1] = c0v.y; vc.position[2] = c0v.z; vc.normal[0] = c0v.w; vc.normal[1] = c1v.x; vc.normal[2] = c1v.y;
     // the clip positions K1 stored for these vertices (what setup and raster saw)
-    const float4 c0 = clip[min(d.vert_base + i0, last_c)], c1 = clip[min(d.vert_base + i1, last_c)],
-                 c2 = clip[min(d.vert_base + i2, last_c)];
+    // whole 16-byte loads: z is not used here, and left alone the compiler narrows each load to an 8-byte
+    // and a 4-byte one — for divergent gathers the cost is per (lane, instruction), not per byte
+    gptr_f32x4 cp = (gptr_f32x4)clip;
+    f32x4 q0 = cp[min(d.vert_base + i0, last_c)], q1 = cp[min(d.vert_base + i1, last_c)], q2 = cp[min(d.vert_base + i2, last_c)];
+    asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2));
+    const float4 c0 = make_float4(q0.x, q0.y, q0.z, q0.w), c1 = make_float4(q1.x, q1.y, q1.z, q1.w),
+                 c2 = make_float4(q2.x, q2.y, q2.z, q2.w);
     // perspective-correct barycentrics: 2D homogeneous edge functions of (x, y, w) at the pixel centre
     // (valid for w <= 0 vertices too)
 #if RND_FAST_SHADE
