@@ -712,9 +712,13 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
             gptr_u32 ix = indices + 3ull * (first_t + local);
             const uint32_t i0 = ix[0], i1 = ix[1], i2 = ix[2];
             if (guard(i0 < nv && i1 < nv && i2 < nv, fb.counters, kGuardSetup)) {
-                const uint4 q0 = *reinterpret_cast<const uint4*>(fb.snap + vb + i0);
-                const uint4 q1 = *reinterpret_cast<const uint4*>(fb.snap + vb + i1);
-                const uint4 q2 = *reinterpret_cast<const uint4*>(fb.snap + vb + i2);
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                u32x4 q0 = *reinterpret_cast<const u32x4*>(fb.snap + vb + i0);
+                u32x4 q1 = *reinterpret_cast<const u32x4*>(fb.snap + vb + i1);
+                u32x4 q2 = *reinterpret_cast<const u32x4*>(fb.snap + vb + i2);
+                // three whole 16-byte gathers in one round trip: left alone the compiler loads the outcodes
+                // first and sinks the positions into the branch that uses them (six gathers, two round trips)
+                asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2));
                 const SnapVert v0{(int32_t)q0.x, (int32_t)q0.y, __uint_as_float(q0.z), q0.w};
                 const SnapVert v1{(int32_t)q1.x, (int32_t)q1.y, __uint_as_float(q1.z), q1.w};
                 const SnapVert v2{(int32_t)q2.x, (int32_t)q2.y, __uint_as_float(q2.z), q2.w};
