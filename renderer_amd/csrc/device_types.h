@@ -24,7 +24,7 @@ constexpr uint32_t kChunkTris = 1024;          // triangles per setup work unit 
 constexpr uint32_t kChunkTrisSmall = 256;      // ... in frames of at most kSmallFrameTris triangles: four times the workgroups,
                                                // one pass each (C1' 4150 -> 5660 frames/s, C2 9300 -> 10000; at C3's 10 M
                                                // triangles the 30 k extra units cost the cull/scan/bin kernels 4 %, C5 18 %)
-constexpr uint32_t kSmallFrameTris = 2u << 20;
+constexpr uint32_t kSmallFrameTris = 2u << 20;   // measured crossover on C2-like grids: 256 wins by 2 % at 1.96 M triangles, loses by 1-2 % at 3.6 M and 5.8 M (RND_SMALL_FRAME_TRIS overrides)
 constexpr uint32_t kVertexBlock = 256;         // vertices per transform workgroup
 constexpr uint32_t kShadowSize = 2048;         // shadow map edge (visual_server.rs:366-367)
 constexpr uint32_t kShadowCascades = 4;        // settings.shadow_cascades (visual_server.rs:88)

@@ -534,7 +534,8 @@ void VisualServer::build_frame(std::vector<DrawItem>& items, std::vector<uint32_
     vert_bases.push_back((uint32_t)vert_base);
     tri_bases.push_back((uint32_t)tri_base);
     fc_.chunk_tris = kChunkTrisSmall;
-    if (tri_base > kSmallFrameTris) {
+    static const uint64_t small_frame_tris = [] { const char* e = std::getenv("RND_SMALL_FRAME_TRIS"); return e ? (uint64_t)std::atoll(e) : (uint64_t)kSmallFrameTris; }();
+    if (tri_base > small_frame_tris) {
         // a large frame: the large chunks of every submesh (they follow the small ones in its table)
         fc_.chunk_tris = kChunkTris;
         unit_base = 0;
