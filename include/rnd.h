@@ -257,7 +257,8 @@ int rnd_detile_gathered(rnd_ctx* ctx, uint32_t world, const void* dev_gathered, 
 /* Sort-last: device pointer of the packed (depth bits << 32 | rgba8) u64 frame, width*height
  * entries, row-major; min-reducing these across ranks is the depth composite. */
 int rnd_packed_device_ptr(rnd_ctx* ctx, void** dev_ptr, uint64_t* n_bytes);
-/* Unpack a (reduced) packed frame on this context's device into its RGBA8 + depth frame. */
+/* Unpack a (reduced) packed frame on this context's device into its RGBA8 frame (the depth stays in the
+ * packed words' upper halves). */
 int rnd_unpack(rnd_ctx* ctx, const void* dev_packed);
 /* Use the caller's HIP stream (hipStream_t as void*) for this context; NULL = own stream.  Shading, present,
  * the 2D overlay, read-backs, detile/unpack and everything the caller enqueues behind rnd_render are ordered

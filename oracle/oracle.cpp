@@ -1222,6 +1222,7 @@ int orc_reset_scene(rnd_ctx* ctx) {
     c->sprite_material.clear();
     c->meshes[orc::QUAD_MESH_ID] = orc::quad_mesh();
     c->fullscreen = 0;          // RenderScene::fullscreen_texture (visual_server.rs:903)
+    c->inv_pv = orc::identity();    // RenderScene::default() (visual_server.rs:579-581, :896-898): cascades of a light set before the next set_camera come from the identity
     return RND_OK;
 }
 

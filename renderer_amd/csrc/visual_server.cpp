@@ -382,6 +382,7 @@ void VisualServer::reset_scene() {
     textures_.clear();
     materials_.clear(); lights_.clear(); mesh_instances_.clear(); mesh_instance_index_.clear(); sprite_materials_.clear();
     fullscreen_ = 0;        // RenderScene::fullscreen_texture (visual_server.rs:903)
+    inv_projection_view_ = Mat4::identity();     // RenderScene::default() (visual_server.rs:579-581, :896-898)
 }
 
 // ---- 2D overlay state ----------------------------------------------------------------------------
@@ -684,6 +685,8 @@ void VisualServer::enqueue_frame(bool want_hdr) {
         d_tile_count_.ensure(2 * need); d_tile_offset_.ensure(need); d_tile_cursor_.ensure(need);
     }
     n_counter_sets_ = 1 + n_passes + (msaa_ - 1);
+    counter_set_ran_.assign(n_counter_sets_, 0);
+    pending_want_hdr_ = want_hdr;
     d_counters_[p].ensure(n_counter_sets_);
     if (h_counter_sets_ < n_counter_sets_) {
         if (frame_pending_) HIP_CHECK(hipStreamSynchronize(stream_));
@@ -854,6 +857,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
             const FrameConst& sfc = consts[1 + k * kShadowCascades + c];
             sfb.frame_const = const_slot(1 + k * kShadowCascades + c);
             clear(sfb, sfc);
+            counter_set_ran_[1 + k * kShadowCascades + c] = 1;
             shadow_layer_clear_[p][k][c] = !casters;
             if (!casters) continue;
             launch_cull(sfb, sfc, gs);
@@ -865,6 +869,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
             launch_raster(sfb, sfc, cap_, gs);
         }
     mark(0, gs);
+    counter_set_ran_[0] = 1;
     clear(fb, fc);                      // visibility words, tile counts, vertex-block flags, frame counters
     launch_cull(fb, fc, gs);       // work units that can reach the view volume and this context's stripes
     launch_transform(fb, fc, gs);
@@ -883,6 +888,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
         FrameBuffers mfb = fb;
         mfb.vis = d_vis_[p].ptr + (size_t)smp * fb.vis_stride;
         mfb.counters = d_counters_[p].ptr + 1 + n_passes + (smp - 1);
+        counter_set_ran_[1 + n_passes + (smp - 1)] = 1;
         const FrameConst& mfc = consts[n_passes + smp];
         mfb.frame_const = const_slot(n_passes + smp);
         clear(mfb, mfc);
@@ -1009,6 +1015,7 @@ void VisualServer::finish() {
         frame_pending_ = false;
         FrameCounters c = h_counters_[0];
         for (uint32_t k = 1; k < n_counter_sets_; ++k) {       // shadow passes share the streams: take the largest demand
+            if (!counter_set_ran_[k]) continue;                 // a skipped cascade: nothing wrote its slot this frame
             const FrameCounters& o = h_counters_[k];
             c.overflow |= o.overflow;
             c.n_records = std::max(c.n_records, o.n_records); c.n_clip = std::max(c.n_clip, o.n_clip);
@@ -1026,7 +1033,7 @@ void VisualServer::finish() {
         if (c.overflow & 4u) cap_.entries = (uint32_t)std::min<uint64_t>((uint64_t)c.n_entries + c.n_entries / 4 + 4096, 0xFFFFFFF0ull);
         grew = 1;
         if (attempt == 7) throw Error(RND_ERR_OOM, "frame does not fit the internal streams");
-        enqueue_frame(false);
+        enqueue_frame(pending_want_hdr_);
     }
     const FrameCounters c = *h_counters_;
     stats_.n_setup = c.n_valid; stats_.n_bin_entries = c.n_entries; stats_.overflow = grew;

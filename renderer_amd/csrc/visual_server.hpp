@@ -183,7 +183,7 @@ private:
     uint32_t event_next_ = 0;
     static constexpr uint64_t kTimingStride = 16;     // a timed frame runs un-overlapped (two serialization points): keep them rare
     // instantiated HIP graphs of the frame's kernel sequence, keyed by the launches' by-value arguments
-    static constexpr int kGraphSlots = 4;
+    static constexpr int kGraphSlots = 8;      // the key cycles through 3 staging blocks x 2 frame parities
     struct CachedGraph { std::vector<uint8_t> key; hipGraphExec_t exec = nullptr; };
     CachedGraph graphs_[kGraphSlots];
     int graph_next_ = 0;
@@ -275,6 +275,8 @@ private:
     Staging staging_[3];
     uint32_t staging_next_ = 0;
     FrameCounters* h_counters_ = nullptr;   // pinned
+    std::vector<uint8_t> counter_set_ran_;    // per counter set of the last frame: its pass ran (a skipped cascade leaves its slot unwritten)
+    bool pending_want_hdr_ = false;           // the frame finish() may have to run again wanted the HDR plane
 
     uint32_t tiles_x_ = 0, tiles_y_ = 0, n_owned_ = 0;
     bool have_frame_ = false, frame_pending_ = false;

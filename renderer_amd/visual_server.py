@@ -145,6 +145,27 @@ class VisualServer:
         self._mesh_ids[handle] = mid
         return mid
 
+    def notify_asset_changes(self, changed_images, asset_server=None):
+        """visual_server.rs:583-619: every changed image that is registered is uploaded again under its
+        handle (update_texture :760-769), then every material that uses one has its data rebuilt
+        (update_render_material_data :710-750).  `changed_images`: iterable of Handle<Image>."""
+        if asset_server is not None:
+            self.asset_server = asset_server
+        changed = [h for h in changed_images if h in self._texture_ids]
+        for h in changed:
+            tid = self._texture_ids.pop(h)
+            image = self.asset_server.get(h)
+            data = np.ascontiguousarray(image.data, dtype=np.uint8)
+            self._check(self.api.register_texture(self._ctx, tid, int(image.width), int(image.height),
+                                                  int(image.mip_level_count), data.ctypes.data))
+            self._texture_ids[h] = tid
+        for mh, mid in list(self._material_ids.items()):
+            material = self.asset_server.get(mh)
+            if material.base_color_image in changed:
+                base = np.asarray(material.base_color.to_array(), dtype=np.float32)
+                self._check(self.api.register_material(self._ctx, mid, _fp(base), int(material.billboard_mode),
+                                                       int(bool(material.unlit)), self._texture_ids[material.base_color_image]))
+
     # -- per-frame state ---------------------------------------------------------------
     def set_camera(self, transform, camera: Camera):
         """visual_server.rs:206-222"""

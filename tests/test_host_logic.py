@@ -175,3 +175,22 @@ def test_batched_instances_equal_single_calls():
         imgs.append((vs.read_triangle_ids(), vs.read_depth()))
     assert (imgs[0][0] == imgs[1][0]).all() and (imgs[0][1] == imgs[1][1]).all()
     assert (imgs[0][0] != 0xFFFFFFFF).sum() > 500
+
+
+def test_reset_scene_puts_the_cascade_camera_back_to_identity():
+    """reset_scene replaces RenderScene with its Default (visual_server.rs:579-581, :896-898), so a light set
+    after it and before the next set_camera takes its cascades from the identity matrix again."""
+    from renderer_amd.types import Light
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    fresh, used = oracle_server(64, 64, threads=1), oracle_server(64, 64, threads=1)
+    used.set_camera(CASES[1][0], CASES[1][1])
+    light_t = from_rotation_x(1.1) @ from_rotation_y(0.3)
+    used.set_light(7, light_t, Light.directional())
+    moved = np.zeros(64, np.float32)
+    assert used.api.get_light_cascades(used._ctx, 7, fp(moved)) == 0
+    used.reset_scene()
+    got, want = np.zeros(64, np.float32), np.zeros(64, np.float32)
+    for vs, out in ((used, got), (fresh, want)):
+        vs.set_light(7, light_t, Light.directional())
+        assert vs.api.get_light_cascades(vs._ctx, 7, fp(out)) == 0
+    assert (got.view(np.uint32) == want.view(np.uint32)).all() and (got != moved).any()

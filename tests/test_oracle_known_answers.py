@@ -688,3 +688,99 @@ def test_ka21_shadow_map_fullscreen_texture():
     # cleared map texels show (2*.5)/(50.5 - 49.5) = 1 -> white; the triangle's texels are darker
     assert (ov[..., 0] == 255).any() and (ov[..., 0] < 255).any()
     assert (ov[..., 0] == ov[..., 1]).all() and (ov[..., 1] == ov[..., 2]).all()
+
+
+# ---- KA22: billboard modes through a material (render_mesh.wgsl:58-79) ------------------------
+
+def blinn_phong_point(frag, n, cam, light_pos, radius, color, intensity):
+    """render_mesh.wgsl:134-181, :256-281 for one point light, in f64 (white base colour)."""
+    frag, n, cam, light_pos = (np.asarray(v, dtype=np.float64) for v in (frag, n, cam, light_pos))
+    n = n / np.linalg.norm(n)
+    d = np.linalg.norm(frag - light_pos)
+    if d > radius:
+        return np.zeros(3)
+    t = min(max((radius - d) / radius, 0.0), 1.0)
+    att = t * t * (3.0 - 2.0 * t)
+    ldir = (frag - light_pos) / d
+    view = (cam - frag) / np.linalg.norm(cam - frag)
+    diff = max(np.dot(n, -ldir), 0.0)
+    h = (-ldir + view) / np.linalg.norm(-ldir + view)
+    spec = max(np.dot(n, h), 0.0) ** 8
+    return np.asarray(color, dtype=np.float64) * intensity * att * (diff + spec)
+
+
+def billboard_scene(mode, unlit, model, w, h, light_pos=None):
+    vs = oracle_server(w, h, threads=1)
+    vs.set_camera(identity(), Camera(aspect_ratio=w / h))
+    mat = vs.asset_server.add(Material(billboard_mode=mode, unlit=unlit))
+    quad = Mesh.quad()
+    quad.submeshes[0].material = mat
+    vs.set_mesh_instance(1, model, vs.asset_server.add(quad))
+    if light_pos is not None:
+        vs.set_light(9, from_translation(light_pos), Light.point(4.0).with_color(Color(1, 1, 1, 2.0)))
+    vs.render()
+    return vs
+
+
+def test_ka22_billboard_fixed_size_covers_a_constant_ndc_square():
+    # mode 2: clip = (ndc(model origin).xy + pos.xy * 0.4, ndc.z, 1): the unit quad always covers the NDC
+    # square of half-size 0.2 around the projected origin, whatever the model's rotation, scale or distance.
+    # 100x50 frame, origin on the axis: x_fb in [40, 60), y_fb in [20, 30) -> exactly 20 x 10 pixels.
+    from renderer_amd.types import from_scale
+    w, h = 100, 50
+    r = 100.0 / 99.95
+    for z, model_rs in ((4.0, from_rotation_y(math.pi) @ from_scale(3.0)), (9.0, from_rotation_y(0.7) @ from_scale((0.1, 5.0, 2.0)))):
+        vs = billboard_scene(2, True, from_translation((0, 0, z)) @ model_rs, w, h)
+        cov = vs.read_coverage()
+        want = np.zeros((h, w), np.uint8)
+        want[20:30, 40:60] = 1
+        assert (cov == want).all()
+        d = vs.read_depth()[cov == 1]
+        assert np.allclose(d, r * (z - 0.05) / z, atol=2e-7) and len(np.unique(d)) == 1      # depth of the origin, flat
+        assert np.allclose(vs.read_color_hdr()[25, 50], [1, 1, 1], rtol=1e-3)                 # unlit white
+
+
+def test_ka22_billboard_fixed_size_lit_keeps_the_vertex_normal_and_the_model_position():
+    # lit mode 2: normal = vertex.normal (0,0,-1) although the model matrix turns it away from the camera
+    # (render_mesh.wgsl:78); frag_pos stays model * pos (:52).  Pixel (50, 25): centre (50.5, 25.5) = NDC
+    # (0.01, -0.02) = origin + pos.xy * 0.4 -> pos = (0.025, -0.05, 0); w = 1 at all corners, so attributes
+    # are linear in screen space.  model = T(0,0,4) Ry(pi) S(3): frag = (-0.075, -0.15, 4).
+    from renderer_amd.types import from_scale
+    w, h = 100, 50
+    model = from_translation((0, 0, 4.0)) @ from_rotation_y(math.pi) @ from_scale(3.0)
+    vs = billboard_scene(2, False, model, w, h, light_pos=(0, 0, 3.0))
+    frag = (model.astype(np.float64) @ np.array([0.025, -0.05, 0.0, 1.0]))[:3]
+    assert np.allclose(frag, [-0.075, -0.15, 4.0], atol=1e-6)
+    want = np.array([0.012, 0.020, 0.036]) + blinn_phong_point(frag, (0, 0, -1), (0, 0, 0), (0, 0, 3.0), 4.0, (1, 1, 1), 2.0)
+    got = vs.read_color_hdr()[25, 50]
+    assert want[0] > 1.0 and np.allclose(got, want, rtol=2e-3), (got, want)
+
+
+def test_ka22_billboard_on_faces_the_camera_with_the_models_normal():
+    # mode 1: world = (cam.x, cam.y, cam.z) * 0.4 | model.w: a 0.4-unit square facing the camera at the model's
+    # origin; rotation and scale of the model are dropped for the position, but the normal stays model * n (:55).
+    # 200x100, default camera at the origin, quad centre (0,0,2): corners (+-0.2, +-0.2, 2);
+    # x_ndc = +-0.2 * (h/2) / 2, y_ndc = +-0.2 * h / 2 with h = 1/tan(0.65):
+    # x_fb = 100 +- 6.5768, y_fb = 50 -+ 6.5768 -> pixel centres 93.5 .. 106.5 and 43.5 .. 56.5 = 14 x 14.
+    from renderer_amd.types import from_scale
+    w, h = 200, 100
+    hh = 1.0 / math.tan(0.65)
+    assert abs(0.2 * hh / 2 * 50 - 6.5768) < 1e-3
+    model = from_translation((0, 0, 2.0)) @ from_rotation_y(0.3) @ from_scale((3.0, 0.5, 2.0))
+    vs = billboard_scene(1, False, model, w, h, light_pos=(0.2, 0.1, 1.0))
+    cov = vs.read_coverage()
+    want = np.zeros((h, w), np.uint8)
+    want[43:57, 93:107] = 1
+    assert (cov == want).all()
+    r = 100.0 / 99.95
+    assert np.allclose(vs.read_depth()[cov == 1], r * (2.0 - 0.05) / 2.0, atol=3e-7)
+    # pixel (100, 50): centre (100.5, 50.5) -> view ray through NDC (0.005, -0.01) at z = 2
+    frag = np.array([0.005 * 2.0 / (hh / 2.0), -0.01 * 2.0 / hh, 2.0])
+    n = (model.astype(np.float64) @ np.array([0, 0, -1.0, 0]))[:3]
+    want_c = np.array([0.012, 0.020, 0.036]) + blinn_phong_point(frag, n, (0, 0, 0), (0.2, 0.1, 1.0), 4.0, (1, 1, 1), 2.0)
+    got = vs.read_color_hdr()[50, 100]
+    assert np.allclose(got, want_c, rtol=3e-3), (got, want_c)
+    # turned away (Ry(pi)): the model's normal points from the camera, so only the ambient term is left
+    vs = billboard_scene(1, False, from_translation((0, 0, 2.0)) @ from_rotation_y(math.pi), w, h, light_pos=(0.2, 0.1, 1.0))
+    assert (vs.read_coverage() == want).all()
+    assert np.allclose(vs.read_color_hdr()[50, 100], [0.012, 0.020, 0.036], rtol=2e-3)
