@@ -102,7 +102,9 @@ def test_set_mesh_instances_batched_10000_then_partial_update():
     for vs in (batched, per_call, cpu):
         vs.render()
     assert batched.frame_stats()["n_draw_items"] == n
-    assert_parity(batched, cpu, min_covered=w * h // 4)
+    # (HDR: sub-pixel quads seen edge-on — the f32 barycentrics of the HIP path against the oracle's f64 move the
+    # specular term by up to two f16 ulps on a few pixels; the 8-bit frame stays within 1 LSB everywhere)
+    assert_parity(batched, cpu, min_covered=w * h // 4, hdr_tol=2 ** -8)
     for fn in ("read_triangle_ids", "read_depth", "read_color_rgba8"):
         assert (getattr(batched, fn)() == getattr(per_call, fn)()).all(), fn
     # partial update in place: every seventh instance moves and swaps its mesh
@@ -116,7 +118,9 @@ def test_set_mesh_instances_batched_10000_then_partial_update():
     for vs in (batched, per_call, cpu):
         vs.render()
     assert batched.frame_stats()["n_draw_items"] == n
-    assert_parity(batched, cpu, min_covered=w * h // 4)
+    # (HDR: sub-pixel quads seen edge-on — the f32 barycentrics of the HIP path against the oracle's f64 move the
+    # specular term by up to two f16 ulps on a few pixels; the 8-bit frame stays within 1 LSB everywhere)
+    assert_parity(batched, cpu, min_covered=w * h // 4, hdr_tol=2 ** -8)
     for fn in ("read_triangle_ids", "read_depth", "read_color_rgba8"):
         assert (getattr(batched, fn)() == getattr(per_call, fn)()).all(), fn
 
