@@ -212,6 +212,25 @@ int rnd_read_overlay_rgba8(rnd_ctx* ctx, uint8_t* dst);
  * Enqueues the whole frame on the context's stream and returns; rnd_finish waits for it. */
 int rnd_render(rnd_ctx* ctx);
 int rnd_finish(rnd_ctx* ctx);
+/* The frame of rnd_render for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same scene state, same kernels, same
+ * pixels as rnd_render, but
+ *  - the image goes to the caller's device buffer `out_rgba8_dev` (row-major width*height*4 bytes; on a tile
+ *    partition the tile-major n_owned_tiles*tile_px*tile_px*4 bytes of rnd_tiles_device_ptr), and
+ *  - every intermediate stream of the frame (table block, clip positions, snapped vertices, visibility words,
+ *    setup records, bin entries, queues, counters) lives in one static 128 MiB device array inside the library
+ *    instead of hipMalloc'ed buffers; its per-device address is looked up once in rnd_create.
+ * The call allocates nothing on the device or in pinned memory and frees nothing.  Limits: the frame's streams
+ * must fit the array (about 1 M triangles at 1920x1080; RND_ERR_INVALID with the sizes otherwise, before
+ * anything is launched); no directional lights (their shadow cascades are 134 MB each), render_size_factor 1,
+ * no 2D overlay (RND_ERR_UNSUPPORTED); the per-frame tables must fit the 1 MiB staging block of rnd_create
+ * (about 4000 draw items).  A frame that overflows an internal stream is not re-run: rnd_finish reports
+ * RND_ERR_OOM and the next frame is laid out with the capacities learnt.  Everything runs on the context's
+ * stream, without the overlap with the previous frame.  All contexts on one GPU share the array and it keeps
+ * the last frame's contents (what must start at zero is cleared by the frame's first kernel): frames through
+ * this entry point must not overlap on one GPU — finish one (or order them on one stream) before the next —
+ * and the read-backs of such a frame (rnd_read_depth / _coverage / _triangle_ids) must come before the next one. */
+int rnd_render_noalloc(rnd_ctx* ctx, void* out_rgba8_dev, uint64_t out_bytes);
 
 /* ---- read-backs (what the reference shows on the surface / in its H/J/K debug views) -- */
 /* final 8-bit sRGB surface image, row-major, origin top-left, width*height*4 bytes */

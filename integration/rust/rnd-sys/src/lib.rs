@@ -101,6 +101,7 @@ extern "C" {
 
     pub fn rnd_render(ctx: *mut rnd_ctx) -> c_int;
     pub fn rnd_finish(ctx: *mut rnd_ctx) -> c_int;
+    pub fn rnd_render_noalloc(ctx: *mut rnd_ctx, out_rgba8_dev: *mut c_void, out_bytes: u64) -> c_int;
 
     pub fn rnd_read_color_rgba8(ctx: *mut rnd_ctx, dst: *mut u8) -> c_int;
     pub fn rnd_read_color_hdr(ctx: *mut rnd_ctx, dst: *mut f32) -> c_int;

@@ -104,6 +104,7 @@ SIGNATURES = {
     "read_overlay_rgba8": (C.c_int, [_P, _P]),
     "render": (C.c_int, [_P]),
     "finish": (C.c_int, [_P]),
+    "render_noalloc": (C.c_int, [_P, _P, C.c_uint64]),
     "read_color_rgba8": (C.c_int, [_P, _P]),
     "read_color_hdr": (C.c_int, [_P, _P]),
     "read_depth": (C.c_int, [_P, _P]),
@@ -125,7 +126,7 @@ SIGNATURES = {
 }
 
 # entry points that only make sense with device memory; a host-only library may omit them
-DEVICE_ONLY = {"mean_timings", "set_tiles_output", "tiles_device_ptr", "detile", "detile_gathered", "packed_device_ptr", "unpack", "set_stream",
+DEVICE_ONLY = {"mean_timings", "render_noalloc", "set_tiles_output", "tiles_device_ptr", "detile", "detile_gathered", "packed_device_ptr", "unpack", "set_stream",
                "color_device_ptr"}
 
 

@@ -164,6 +164,9 @@ int rnd_read_overlay_rgba8(rnd_ctx* ctx, uint8_t* dst) {
 }
 
 int rnd_render(rnd_ctx* ctx) { return guard(ctx, [&](rnd::VisualServer& v) { v.render(); }); }
+int rnd_render_noalloc(rnd_ctx* ctx, void* out_dev, uint64_t out_bytes) {
+    return guard(ctx, [&](rnd::VisualServer& v) { v.render_noalloc(out_dev, out_bytes); });
+}
 int rnd_finish(rnd_ctx* ctx) { return guard(ctx, [&](rnd::VisualServer& v) { v.finish(); }); }
 
 int rnd_read_color_rgba8(rnd_ctx* ctx, uint8_t* dst) { return guard(ctx, [&](rnd::VisualServer& v) { v.read_color_rgba8(dst); }); }

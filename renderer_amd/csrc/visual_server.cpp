@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cstring>
 #include <limits>
+#include <mutex>
 
 namespace rnd {
 
@@ -41,6 +42,31 @@ void DeviceBuffer<T>::release() {
 
 static constexpr uint32_t kQuadMeshId = 0xFFFFFFFEu;
 
+// ---- the scratch array of the no-allocation frame (rnd_render_noalloc) --------------------------
+// Every per-frame intermediate stream of a frame rendered through rnd_render_noalloc (table block, clip
+// positions, snapped vertices, visibility words, setup records, bin entries, queues, counters) is carved
+// out of this one file-scope array instead of hipMalloc'ed buffers.  Each GPU the library is used on holds
+// its own copy at its own address until the process ends.  In host code the array's NAME is only a stand-in
+// for hipGetSymbolAddress: the per-device address is looked up once per device (below, from the constructor,
+// with that device current) and every launch, memset and copy takes that pointer.
+static __device__ __align__(256) unsigned char scratch[VisualServer::kScratchBytes];
+static constexpr int kMaxScratchDevices = 64;
+static void* g_scratch_ptr[kMaxScratchDevices] = {};
+static std::mutex g_scratch_mutex;
+
+// call with `device` current
+static uint8_t* scratch_of_device(int device) {
+    if (device < 0 || device >= kMaxScratchDevices) throw Error(RND_ERR_INVALID, "device ordinal beyond the scratch table");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* ptr = nullptr;
+        HIP_CHECK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) throw Error(RND_ERR_DEVICE, "hipGetSymbolAddress returned a null scratch address");
+        g_scratch_ptr[device] = ptr;
+    }
+    return static_cast<uint8_t*>(g_scratch_ptr[device]);
+}
+
 VisualServer::VisualServer(uint32_t width, uint32_t height, int device) : device_(device), width_(width), height_(height) {
     if (width == 0 || height == 0 || width > kMaxRenderSize || height > kMaxRenderSize)
         throw Error(RND_ERR_INVALID, "render size must be in 1..8192");
@@ -54,7 +80,15 @@ VisualServer::VisualServer(uint32_t width, uint32_t height, int device) : device
     for (auto& es : event_sets_)
         for (auto& e : es.ev) HIP_CHECK(hipEventCreate(&e));
     for (auto& s : staging_) HIP_CHECK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
-    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_counters_), sizeof(FrameCounters), hipHostMallocDefault));
+    scratch_ = scratch_of_device(device_);
+    // pinned blocks sized so that the no-allocation frame never has to grow them
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_counters_), kPinnedCounterSets * sizeof(FrameCounters), hipHostMallocDefault));
+    h_counter_sets_ = kPinnedCounterSets;
+    for (auto& st : staging_) {
+        HIP_CHECK(hipHostMalloc(&st.host, kStagingBytes, hipHostMallocMapped | hipHostMallocPortable));
+        HIP_CHECK(hipHostGetDevicePointer(&st.host_dev, st.host, 0));
+        st.bytes = kStagingBytes;
+    }
     d_counters_[0].ensure(1); d_counters_[1].ensure(1);
     HIP_CHECK(hipStreamCreateWithFlags(&geo_stream_, hipStreamNonBlocking));     // (a higher or lower stream priority changes nothing measurable)
     for (int k = 0; k < 2; ++k) {
@@ -636,7 +670,19 @@ void VisualServer::sample_shift(uint32_t smp, int32_t& dx, int32_t& dy) {
     dy = kSub / 2 - k16[smp & 3][1] * (kSub / 16);
 }
 
-void VisualServer::enqueue_frame(bool want_hdr) {
+// A bump allocator over the static scratch array: sizes are added up first (nothing is dereferenced), the
+// frame is rejected before any launch when the sum exceeds the array.
+struct ScratchArena {
+    uint8_t* base; size_t size; size_t used = 0;
+    template <class T> T* take(size_t n) {
+        const size_t off = (used + 255) / 256 * 256;
+        used = off + std::max<size_t>(n, 1) * sizeof(T);
+        return reinterpret_cast<T*>(base + off);
+    }
+};
+
+void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t noalloc_bytes) {
+    const bool noalloc = noalloc_out != nullptr;
     static const bool prof = std::getenv("RND_HOST_PROFILE") != nullptr;
     static double acc[6]; static uint32_t acc_n;
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -645,16 +691,16 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     use_device();
     if (scaled()) want_hdr = true;      // the present pass samples the HDR target
     const uint32_t p = parity_ ^ 1u;    // this frame's copy of the buffers that geometry writes and shading reads
-    parity_ = p;
     // Overlap pays when there is shading to hide the geometry chain behind: the hand-over between the two
     // streams costs ~25 us per frame (measured: C3 +6 %, C4 +4 %, C2 +2 %; C1', 20 us of shading, -8 %),
     // so frames whose last measured shading time is below 30 us stay on one stream.
-    const bool overlap = overlap_ && !(have_timings_ && timings_.shade_ms < 0.03f);
+    const bool overlap = overlap_ && !noalloc && !(have_timings_ && timings_.shade_ms < 0.03f);
     hipStream_t const gs = overlap ? geo_stream_ : stream_;      // the geometry phase's stream
-    std::vector<DrawItem> items;
-    std::vector<uint32_t> vert_bases, tri_bases, unit_bases;
-    std::vector<GpuLight> lights;
-    std::vector<DrawItem> shadow_items;
+    std::vector<DrawItem>& items = items_;
+    std::vector<uint32_t>&vert_bases = vert_bases_, &tri_bases = tri_bases_, &unit_bases = unit_bases_;
+    std::vector<GpuLight>& lights = gpu_lights_;
+    std::vector<DrawItem>& shadow_items = shadow_items_;
+    items.clear(); vert_bases.clear(); tri_bases.clear(); unit_bases.clear(); lights.clear(); shadow_items.clear();
     build_frame(items, vert_bases, tri_bases, unit_bases, lights, shadow_items);
     // every directional light owns a cascade set (the reference also fills maps for point lights,
     // which its shader never reads: visual_server.rs:358-436, render_mesh.wgsl:150-152)
@@ -665,6 +711,17 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     if (!n_sets) for (auto& l : lights) l.shadow_index = -1;
     const uint32_t n_passes = n_sets * kShadowCascades;
     constexpr uint32_t kShadowTiles = (kShadowSize / kTile) * (kShadowSize / kTile);
+    const bool overlay = fullscreen_ != 0 || !uiboxes_.empty() || !glyphs_.empty();
+    if (noalloc) {
+        // what the scratch array cannot hold or what would need a new allocation
+        if (n_sets) throw Error(RND_ERR_UNSUPPORTED, "rnd_render_noalloc: directional lights need 134 MB of shadow cascades each, beyond the scratch array");
+        if (scaled()) throw Error(RND_ERR_UNSUPPORTED, "rnd_render_noalloc: render_size_factor != 1 needs an HDR plane");
+        if (overlay) throw Error(RND_ERR_UNSUPPORTED, "rnd_render_noalloc: the 2D overlay is not available here");
+        if (want_packed_ && d_packed_.count < (size_t)width_ * height_) throw Error(RND_ERR_UNSUPPORTED, "rnd_render_noalloc: the packed frame has not been allocated for this size");
+        const uint64_t need_out = world_ > 1 ? (uint64_t)n_owned_ * kTilePixels * 4 : (uint64_t)width_ * height_ * 4;
+        if (noalloc_bytes < need_out) throw Error(RND_ERR_INVALID, "rnd_render_noalloc: output buffer too small");
+        if (1 + (msaa_ - 1) > kPinnedCounterSets) throw Error(RND_ERR_UNSUPPORTED, "rnd_render_noalloc: too many passes");
+    }
     std::vector<ShadowSet> sets(n_sets);
     if (n_sets) {
         if (shadow_layers_[p].size() < n_sets) shadow_layers_[p].resize(n_sets);
@@ -684,16 +741,15 @@ void VisualServer::enqueue_frame(bool want_hdr) {
         const size_t need = std::max<size_t>((size_t)tiles_x_ * tiles_y_, kShadowTiles);
         d_tile_count_.ensure(2 * need); d_tile_offset_.ensure(need); d_tile_cursor_.ensure(need);
     }
-    n_counter_sets_ = 1 + n_passes + (msaa_ - 1);
-    counter_set_ran_.assign(n_counter_sets_, 0);
-    pending_want_hdr_ = want_hdr;
-    d_counters_[p].ensure(n_counter_sets_);
-    if (h_counter_sets_ < n_counter_sets_) {
+    // (members that describe "the last enqueued frame" change only after the last point where this one can be rejected)
+    const uint32_t n_counter_sets = 1 + n_passes + (msaa_ - 1);
+    if (!noalloc) d_counters_[p].ensure(n_counter_sets);
+    if (h_counter_sets_ < n_counter_sets) {
         if (frame_pending_) HIP_CHECK(hipStreamSynchronize(stream_));
         if (h_counters_) HIP_CHECK(hipHostFree(h_counters_));
         h_counters_ = nullptr;
-        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_counters_), n_counter_sets_ * sizeof(FrameCounters), hipHostMallocDefault));
-        h_counter_sets_ = n_counter_sets_;
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_counters_), n_counter_sets * sizeof(FrameCounters), hipHostMallocDefault));
+        h_counter_sets_ = n_counter_sets;
     }
     const FrameConst& fc = fc_;
     const size_t n_tiles = (size_t)tiles_x_ * tiles_y_;
@@ -705,20 +761,50 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     if (cap_.clip_queue < std::max<uint32_t>(fc.n_tris / 8, 65536)) cap_.clip_queue = std::max<uint32_t>(fc.n_tris / 8, 65536);
     const uint64_t want_entries = std::max<uint64_t>(4ull * cap_.records + 16ull * n_tiles, 1u << 20);
     if (cap_.entries < want_entries) cap_.entries = (uint32_t)std::min<uint64_t>(want_entries, 0xFFFFFFF0ull);
-    d_clip_[p].ensure(std::max<size_t>(fc.n_verts, 1));
-    d_snap_.ensure(std::max<size_t>(fc.n_verts, 1));
-    d_records_.ensure(cap_.records); d_tilewords_.ensure(2 * (size_t)cap_.records);
-    d_clip_queue_.ensure(cap_.clip_queue);
-    d_chunk_count_.ensure(std::max<size_t>(2 * (size_t)fc.n_units, 2));
-    d_active_units_.ensure(std::max<size_t>(2 * (size_t)fc.n_units, 2));
-    d_vblock_needed_.ensure((size_t)fc.n_verts / kVertexBlock + 2);
-    d_entries_.ensure(cap_.entries);
-    d_wide_list_.ensure(cap_.wide_list);
-    d_tile_slices_.ensure(std::max<size_t>(n_tiles, n_sets ? kShadowTiles : 0));
-    d_raster_extra_.ensure(kRasterExtraCap);
-    if (world_ > 1) d_tiles_.ensure(std::max<size_t>((size_t)n_owned_ * kTilePixels * 4, 4));
-    if (want_packed_) d_packed_.ensure((size_t)width_ * height_);
-    if (want_hdr) d_hdr_.ensure((size_t)width_ * height_ * 3);
+    // the per-frame intermediate streams: hipMalloc'ed buffers that grow on demand, or — for the no-allocation
+    // frame — slices of the static scratch array
+    ScratchArena arena{scratch_, kScratchBytes};
+    struct {
+        float4* clip; SnapVert* snap; SetupRecord* records; uint32_t *tilewords, *clip_queue, *chunk_count, *active_units, *vblock_needed, *entries,
+            *wide_list, *tile_slices, *tile_count, *tile_offset, *tile_cursor;
+        uint2* raster_extra; FrameCounters* counters; uint64_t* vis;
+    } bp{};
+    const size_t n_vblocks = (size_t)fc.n_verts / kVertexBlock + 2;
+    if (noalloc) {
+        bp.clip = arena.take<float4>(fc.n_verts); bp.snap = arena.take<SnapVert>(fc.n_verts);
+        bp.records = arena.take<SetupRecord>(cap_.records); bp.tilewords = arena.take<uint32_t>(2 * (size_t)cap_.records);
+        bp.clip_queue = arena.take<uint32_t>(cap_.clip_queue);
+        bp.chunk_count = arena.take<uint32_t>(std::max<size_t>(2 * (size_t)fc.n_units, 2));
+        bp.active_units = arena.take<uint32_t>(std::max<size_t>(2 * (size_t)fc.n_units, 2));
+        bp.vblock_needed = arena.take<uint32_t>(n_vblocks);
+        bp.entries = arena.take<uint32_t>(cap_.entries);
+        bp.wide_list = arena.take<uint32_t>(cap_.wide_list);
+        bp.tile_slices = arena.take<uint32_t>(n_tiles);
+        bp.raster_extra = arena.take<uint2>(kRasterExtraCap);
+        bp.tile_count = arena.take<uint32_t>(2 * n_tiles); bp.tile_offset = arena.take<uint32_t>(n_tiles); bp.tile_cursor = arena.take<uint32_t>(n_tiles);
+        bp.counters = arena.take<FrameCounters>(n_counter_sets);
+        bp.vis = arena.take<uint64_t>(n_tiles * kTilePixels * msaa_);
+    } else {
+        d_clip_[p].ensure(std::max<size_t>(fc.n_verts, 1));
+        d_snap_.ensure(std::max<size_t>(fc.n_verts, 1));
+        d_records_.ensure(cap_.records); d_tilewords_.ensure(2 * (size_t)cap_.records);
+        d_clip_queue_.ensure(cap_.clip_queue);
+        d_chunk_count_.ensure(std::max<size_t>(2 * (size_t)fc.n_units, 2));
+        d_active_units_.ensure(std::max<size_t>(2 * (size_t)fc.n_units, 2));
+        d_vblock_needed_.ensure(n_vblocks);
+        d_entries_.ensure(cap_.entries);
+        d_wide_list_.ensure(cap_.wide_list);
+        d_tile_slices_.ensure(std::max<size_t>(n_tiles, n_sets ? kShadowTiles : 0));
+        d_raster_extra_.ensure(kRasterExtraCap);
+        if (world_ > 1) d_tiles_.ensure(std::max<size_t>((size_t)n_owned_ * kTilePixels * 4, 4));
+        if (want_packed_) d_packed_.ensure((size_t)width_ * height_);
+        if (want_hdr) d_hdr_.ensure((size_t)width_ * height_ * 3);
+        bp.clip = d_clip_[p].ptr; bp.snap = d_snap_.ptr; bp.records = d_records_.ptr; bp.tilewords = d_tilewords_.ptr; bp.clip_queue = d_clip_queue_.ptr;
+        bp.chunk_count = d_chunk_count_.ptr; bp.active_units = d_active_units_.ptr; bp.vblock_needed = d_vblock_needed_.ptr; bp.entries = d_entries_.ptr;
+        bp.wide_list = d_wide_list_.ptr; bp.tile_slices = d_tile_slices_.ptr; bp.raster_extra = d_raster_extra_.ptr;
+        bp.tile_count = d_tile_count_.ptr; bp.tile_offset = d_tile_offset_.ptr; bp.tile_cursor = d_tile_cursor_.ptr;
+        bp.counters = d_counters_[p].ptr; bp.vis = d_vis_[p].ptr;
+    }
 
     // stage the per-frame tables in pinned memory and upload them
     const size_t off_items = 0;
@@ -730,7 +816,8 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     const size_t off_ss = align_up(off_si + (n_sets ? shadow_items.size() * sizeof(DrawItem) : 0), 256);
     // the constants of every pass of the frame: [0] main pass (sample 0), then one per shadow pass,
     // then one per further MSAA sample
-    std::vector<FrameConst> consts(1 + n_passes + (msaa_ - 1), fc);
+    std::vector<FrameConst>& consts = consts_;
+    consts.assign(1 + n_passes + (msaa_ - 1), fc);
     for (uint32_t k = 0; k < n_sets; ++k)
         for (uint32_t c = 0; c < kShadowCascades; ++c) {
             FrameConst& sfc = consts[1 + k * kShadowCascades + c];
@@ -743,13 +830,27 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     constexpr size_t kConstSlot = (sizeof(FrameConst) + 255) / 256 * 256;
     const size_t off_fc = align_up(off_ss + n_sets * sizeof(ShadowSet), 256);
     // the 2D pass's quads, when anything 2D is set
-    const bool overlay = fullscreen_ != 0 || !uiboxes_.empty() || !glyphs_.empty();
     std::vector<Prim2D> prims;
     if (overlay) build_prims(prims);
     const size_t off_pr = align_up(off_fc + consts.size() * kConstSlot, 256);
     const size_t total = align_up(off_pr + prims.size() * sizeof(Prim2D) + 256, 256);
     lap(0);
     Staging& st = staging_[staging_next_];
+    size_t tables_off = 0;
+    if (st.bytes < total && noalloc) throw Error(RND_ERR_INVALID, "rnd_render_noalloc: the frame's tables (draw items, lights) exceed the 1 MiB staging block allocated at rnd_create");
+    if (noalloc) {
+        tables_off = static_cast<size_t>(arena.take<uint8_t>(total) - scratch_);       // the device copy of the tables
+        if (arena.used > arena.size) {
+            char msg[200];
+            std::snprintf(msg, sizeof msg, "rnd_render_noalloc: this frame's intermediate streams need %zu bytes, the static scratch array holds %zu "
+                          "(roughly 1 M triangles at 1080p)", arena.used, arena.size);
+            throw Error(RND_ERR_INVALID, msg);
+        }
+    }
+    // nothing below rejects the frame
+    parity_ = p;
+    n_counter_sets_ = n_counter_sets;
+    counter_set_ran_.assign(n_counter_sets_, 0);
     staging_next_ = (staging_next_ + 1) % 3;
     if (st.in_flight) { HIP_CHECK(hipEventSynchronize(st.done)); st.in_flight = false; }
     if (st.bytes < total) {
@@ -777,8 +878,13 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     overlay_drawn_ = overlay;
     // one device block with the same layout; the frame's first clear kernel copies it over from the
     // pinned block (no hipMemcpyAsync: each one costs the host ~8 us and the GPU a blit kernel)
-    d_tables_[p].ensure(total + total / 2);
-    uint8_t* const tb = d_tables_[p].ptr;
+    uint8_t* tb;
+    if (noalloc) {
+        tb = scratch_ + tables_off;
+    } else {
+        d_tables_[p].ensure(total + total / 2);
+        tb = d_tables_[p].ptr;
+    }
 
     lap(2);
     FrameBuffers fb{};
@@ -794,17 +900,20 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     // record/bin/raster path; C3 and C5 do not move; 64 gains nothing more and costs C1
     static const uint32_t direct_pixels = [] { const char* e = std::getenv("RND_DIRECT_PIXELS"); int v = e ? std::atoi(e) : (int)kDirectPixels; return (uint32_t)std::min(std::max(v, 0), 64); }();
     fb.direct_pixels = direct_pixels;
-    fb.clip = d_clip_[p].ptr; fb.snap = d_snap_.ptr; fb.records = d_records_.ptr; fb.tilewords = reinterpret_cast<uint2*>(d_tilewords_.ptr); fb.clip_queue = d_clip_queue_.ptr;
-    fb.chunk_count = d_chunk_count_.ptr;
-    fb.unit_bases = reinterpret_cast<const uint32_t*>(tb + off_ub); fb.active_units = reinterpret_cast<uint2*>(d_active_units_.ptr); fb.vblock_needed = d_vblock_needed_.ptr;
-    fb.tile_count = d_tile_count_.ptr; fb.tile_offset = d_tile_offset_.ptr; fb.tile_cursor = d_tile_cursor_.ptr;
-    fb.wide_list = d_wide_list_.ptr; fb.tile_slices = d_tile_slices_.ptr; fb.raster_extra = d_raster_extra_.ptr;
-    fb.entries = d_entries_.ptr; fb.counters = d_counters_[p].ptr;
+    fb.clip = bp.clip; fb.snap = bp.snap; fb.records = bp.records; fb.tilewords = reinterpret_cast<uint2*>(bp.tilewords); fb.clip_queue = bp.clip_queue;
+    fb.chunk_count = bp.chunk_count;
+    fb.unit_bases = reinterpret_cast<const uint32_t*>(tb + off_ub); fb.active_units = reinterpret_cast<uint2*>(bp.active_units); fb.vblock_needed = bp.vblock_needed;
+    fb.tile_count = bp.tile_count; fb.tile_offset = bp.tile_offset; fb.tile_cursor = bp.tile_cursor;
+    fb.wide_list = bp.wide_list; fb.tile_slices = bp.tile_slices; fb.raster_extra = bp.raster_extra;
+    fb.entries = bp.entries; fb.counters = bp.counters;
     fb.launch_order = d_launch_order_.ptr; fb.n_owned = n_owned_;
-    fb.vis = d_vis_[p].ptr;
+    fb.vis = bp.vis;
     fb.vis_stride = (uint64_t)tiles_x_ * tiles_y_ * kTilePixels;
-    fb.frame_rgba8 = (world_ > 1 || scaled()) ? nullptr : d_frame_.ptr;
-    fb.tiles_rgba8 = world_ > 1 ? (ext_tiles_ ? ext_tiles_ : d_tiles_.ptr) : nullptr;
+    fb.frame_rgba8 = (world_ > 1 || scaled()) ? nullptr : (noalloc ? noalloc_out : d_frame_.ptr);
+    fb.tiles_rgba8 = world_ > 1 ? (noalloc ? noalloc_out : ext_tiles_ ? ext_tiles_ : d_tiles_.ptr) : nullptr;
+    last_noalloc_ = noalloc; last_counters_ = bp.counters; last_vis_ = bp.vis; pending_want_hdr_ = want_hdr;
+    last_frame_out_ = noalloc && world_ <= 1 ? noalloc_out : d_frame_.ptr;
+    last_tiles_out_ = fb.tiles_rgba8;
     fb.packed = want_packed_ ? d_packed_.ptr : nullptr;
     fb.hdr = want_hdr ? d_hdr_.ptr : nullptr;
 
@@ -850,7 +959,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
             if (!casters && shadow_layer_clear_[p][k][c]) continue;
             FrameBuffers sfb = fb;
             sfb.items = reinterpret_cast<const DrawItem*>(tb + off_si); sfb.lights = nullptr; sfb.shadow_sets = nullptr; sfb.alpha_test = 0;
-            sfb.counters = d_counters_[p].ptr + 1 + k * kShadowCascades + c;
+            sfb.counters = bp.counters + 1 + k * kShadowCascades + c;
             sfb.launch_order = d_shadow_order_.ptr; sfb.n_owned = kShadowTiles;
             sfb.vis = shadow_layers_[p][k].ptr + (size_t)c * kShadowTiles * kTilePixels;
             sfb.frame_rgba8 = nullptr; sfb.tiles_rgba8 = nullptr; sfb.packed = nullptr; sfb.hdr = nullptr;
@@ -886,8 +995,8 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     // vertices moved so that the sample sits on the pixel centre (clip positions are shared)
     for (uint32_t smp = 1; smp < msaa_; ++smp) {
         FrameBuffers mfb = fb;
-        mfb.vis = d_vis_[p].ptr + (size_t)smp * fb.vis_stride;
-        mfb.counters = d_counters_[p].ptr + 1 + n_passes + (smp - 1);
+        mfb.vis = bp.vis + (size_t)smp * fb.vis_stride;
+        mfb.counters = bp.counters + 1 + n_passes + (smp - 1);
         counter_set_ran_[1 + n_passes + (smp - 1)] = 1;
         const FrameConst& mfc = consts[n_passes + smp];
         mfb.frame_const = const_slot(n_passes + smp);
@@ -913,7 +1022,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
         op.srgb_lut = d_srgb_lut_.ptr;
         op.font = TextureDesc{d_font_.ptr, font_w_, font_h_, 1u, 0u};
         op.fullscreen = (uint32_t)fullscreen_;
-        if (fullscreen_ == 1) { op.depth_src = d_vis_[p].ptr; op.src_w = width_; op.src_h = height_; op.src_tiles_x = tiles_x_; }
+        if (fullscreen_ == 1) { op.depth_src = bp.vis; op.src_w = width_; op.src_h = height_; op.src_tiles_x = tiles_x_; }
         else if (fullscreen_ == 2) {
             for (uint32_t k = 0; k < n_sets; ++k)
                 if (lights_[shadowed[k]].id == fullscreen_light_) {
@@ -939,7 +1048,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
     // the replay costs the host as much as the launches (25.7 vs 30.1 us of 61 us per frame) and the
     // frame rate does not move, so the plain launches stay the default.
     bool launched = false;
-    if (use_graphs_ && !timed && !overlay && !overlap && !n_sets) {
+    if (use_graphs_ && !timed && !overlay && !overlap && !n_sets && !noalloc) {
         std::vector<uint8_t> key;
         auto add = [&](const void* p, size_t n) { const uint8_t* b = static_cast<const uint8_t*>(p); key.insert(key.end(), b, b + n); };
         add(&fb, sizeof fb); add(&cap_, sizeof cap_);
@@ -948,7 +1057,7 @@ void VisualServer::enqueue_frame(bool want_hdr) {
             add(dims, sizeof dims);
         }
         for (uint32_t k = 0; k < n_sets; ++k) { const void* lp = shadow_layers_[p][k].ptr; add(&lp, sizeof lp); }
-        const void* ptrs[8] = {d_counters_[p].ptr, d_vis_[p].ptr, d_hdr_.ptr, d_present_.ptr, d_shadow_order_.ptr, tb, h, reinterpret_cast<const void*>(total)};
+        const void* ptrs[8] = {bp.counters, bp.vis, d_hdr_.ptr, d_present_.ptr, d_shadow_order_.ptr, tb, h, reinterpret_cast<const void*>(total)};
         add(ptrs, sizeof ptrs);
         const uint64_t misc[10] = {off_si, off_fc, n_sets, msaa_, surface_w_, surface_h_, width_, height_, tone_mapping_, render_size_factor_ > 1.0f ? 1u : 0u};
         add(misc, sizeof misc);
@@ -1005,12 +1114,21 @@ void VisualServer::enqueue_frame(bool want_hdr) {
 
 void VisualServer::render() { enqueue_frame(false); }
 
+// rnd_render_noalloc: the same frame with every intermediate stream in the static scratch array and the image in
+// the caller's buffer.  No hipMalloc/hipFree/hipHostMalloc on this path (pinned blocks and events date from the
+// constructor; the host tables reuse their capacity after the first frames).  One stream, no overlap with the
+// previous frame: every context on this GPU shares the array, so calls that overlap on one GPU race.
+void VisualServer::render_noalloc(void* out_dev, uint64_t out_bytes) {
+    if (!out_dev) throw Error(RND_ERR_INVALID, "rnd_render_noalloc: null output buffer");
+    enqueue_frame(false, static_cast<uint8_t*>(out_dev), out_bytes);
+}
+
 void VisualServer::finish() {
     if (!frame_pending_) return;
     use_device();
     uint32_t grew = 0;
     for (int attempt = 0; attempt < 8; ++attempt) {
-        HIP_CHECK(hipMemcpyAsync(h_counters_, d_counters_[parity_].ptr, n_counter_sets_ * sizeof(FrameCounters), hipMemcpyDeviceToHost, stream_));
+        HIP_CHECK(hipMemcpyAsync(h_counters_, last_counters_, n_counter_sets_ * sizeof(FrameCounters), hipMemcpyDeviceToHost, stream_));
         HIP_CHECK(hipStreamSynchronize(stream_));
         frame_pending_ = false;
         FrameCounters c = h_counters_[0];
@@ -1032,6 +1150,13 @@ void VisualServer::finish() {
         if (c.overflow & 2u) cap_.clip_queue = (uint32_t)std::min<uint64_t>((uint64_t)c.n_clip + c.n_clip / 4 + 4096, 0xFFFFFFF0ull);
         if (c.overflow & 4u) cap_.entries = (uint32_t)std::min<uint64_t>((uint64_t)c.n_entries + c.n_entries / 4 + 4096, 0xFFFFFFF0ull);
         grew = 1;
+        if (last_noalloc_) {
+            // growing means allocating: the frame in the caller's buffer is incomplete and stays so; the next
+            // frame (either entry point) is laid out with the capacities learnt here
+            have_frame_ = false;
+            throw Error(RND_ERR_OOM, "rnd_render_noalloc: the frame overflowed an internal stream (records, clip queue or bin entries); "
+                                     "render it again, or once through rnd_render");
+        }
         if (attempt == 7) throw Error(RND_ERR_OOM, "frame does not fit the internal streams");
         enqueue_frame(pending_want_hdr_);
     }
@@ -1101,10 +1226,10 @@ void VisualServer::read_color_rgba8(uint8_t* dst) {
     finish(); need_frame(); use_device();
     if (world_ > 1) {   // a partitioned context holds only its tiles: assemble them over a cleared frame
         HIP_CHECK(hipMemsetAsync(d_frame_.ptr, 0, (size_t)width_ * height_ * 4, stream_));
-        detile(rank_, world_, ext_tiles_ ? ext_tiles_ : d_tiles_.ptr);
+        detile(rank_, world_, last_tiles_out_);
     }
     if (scaled()) HIP_CHECK(hipMemcpyAsync(dst, d_present_.ptr, (size_t)surface_w_ * surface_h_ * 4, hipMemcpyDeviceToHost, stream_));
-    else HIP_CHECK(hipMemcpyAsync(dst, d_frame_.ptr, (size_t)width_ * height_ * 4, hipMemcpyDeviceToHost, stream_));
+    else HIP_CHECK(hipMemcpyAsync(dst, world_ > 1 ? d_frame_.ptr : last_frame_out_, (size_t)width_ * height_ * 4, hipMemcpyDeviceToHost, stream_));
     HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
@@ -1131,7 +1256,7 @@ void VisualServer::read_planes(float* depth, uint32_t* ids, uint8_t* coverage) {
         if (depth) { d_depth.ensure(n); HIP_CHECK(hipMemsetAsync(d_depth.ptr, 0, n * 4, stream_)); }
         if (ids) { d_ids.ensure(n); HIP_CHECK(hipMemsetAsync(d_ids.ptr, 0xFF, n * 4, stream_)); }
         if (coverage) { d_cov.ensure(n); HIP_CHECK(hipMemsetAsync(d_cov.ptr, 0, n, stream_)); }
-        launch_extract(d_vis_[parity_].ptr, d_launch_order_.ptr, n_owned_, fc_, d_depth.ptr, d_ids.ptr, d_cov.ptr, stream_);
+        launch_extract(last_vis_, d_launch_order_.ptr, n_owned_, fc_, d_depth.ptr, d_ids.ptr, d_cov.ptr, stream_);
         if (depth) HIP_CHECK(hipMemcpyAsync(depth, d_depth.ptr, n * 4, hipMemcpyDeviceToHost, stream_));
         if (ids) HIP_CHECK(hipMemcpyAsync(ids, d_ids.ptr, n * 4, hipMemcpyDeviceToHost, stream_));
         if (coverage) HIP_CHECK(hipMemcpyAsync(coverage, d_cov.ptr, n, hipMemcpyDeviceToHost, stream_));
@@ -1209,6 +1334,7 @@ void VisualServer::unpack(const void* dev_packed) {
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(stream_));
     have_frame_ = true;
+    last_frame_out_ = d_frame_.ptr;
 }
 
 void VisualServer::set_stream(hipStream_t s) {

@@ -121,7 +121,9 @@ public:
 
     // frame — visual_server.rs:224-311
     void render();
+    void render_noalloc(void* out_dev, uint64_t out_bytes);
     void finish();
+    static constexpr size_t kScratchBytes = 128ull << 20;      // the static device array behind render_noalloc
 
     // read-backs
     void read_color_rgba8(uint8_t* dst);
@@ -154,7 +156,7 @@ private:
     void build_frame(std::vector<DrawItem>& items, std::vector<uint32_t>& vert_bases, std::vector<uint32_t>& tri_bases,
                      std::vector<uint32_t>& unit_bases,
                      std::vector<GpuLight>& lights, std::vector<DrawItem>& shadow_items);
-    void enqueue_frame(bool want_hdr);
+    void enqueue_frame(bool want_hdr, uint8_t* noalloc_out = nullptr, uint64_t noalloc_bytes = 0);
     void need_frame() const;
 
     int device_;
@@ -275,8 +277,22 @@ private:
     Staging staging_[3];
     uint32_t staging_next_ = 0;
     FrameCounters* h_counters_ = nullptr;   // pinned
+    static constexpr uint32_t kPinnedCounterSets = 16;        // allocated at construction (one set per pass of a frame)
+    static constexpr size_t kStagingBytes = 1u << 20;         // each staging block at construction (~4000 draw items)
+    // no-allocation frame: this device's address of the static scratch array; what the last frame used
+    uint8_t* scratch_ = nullptr;
+    bool last_noalloc_ = false;
+    const FrameCounters* last_counters_ = nullptr;
+    const uint64_t* last_vis_ = nullptr;
+    const uint8_t* last_frame_out_ = nullptr;
     std::vector<uint8_t> counter_set_ran_;    // per counter set of the last frame: its pass ran (a skipped cascade leaves its slot unwritten)
     bool pending_want_hdr_ = false;           // the frame finish() may have to run again wanted the HDR plane
+    const uint8_t* last_tiles_out_ = nullptr;
+    // the per-frame host tables, kept between frames so that a steady state allocates nothing on the host either
+    std::vector<DrawItem> items_, shadow_items_;
+    std::vector<uint32_t> vert_bases_, tri_bases_, unit_bases_;
+    std::vector<GpuLight> gpu_lights_;
+    std::vector<FrameConst> consts_;
 
     uint32_t tiles_x_ = 0, tiles_y_ = 0, n_owned_ = 0;
     bool have_frame_ = false, frame_pending_ = false;

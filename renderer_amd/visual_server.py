@@ -272,6 +272,11 @@ class VisualServer:
     def finish(self):
         self._check(self.api.finish(self._ctx))
 
+    def render_noalloc(self, out_dev_ptr, out_bytes):
+        """rnd_render_noalloc: the frame into the caller's device buffer, intermediates in the library's static
+        scratch array (no allocation; no counterpart in the reference)."""
+        self._check(self.api.render_noalloc(self._ctx, C.c_void_p(out_dev_ptr), int(out_bytes)))
+
     # -- read-backs ----------------------------------------------------------------------
     def _read(self, fn, shape, dtype):
         out = np.empty(shape, dtype=dtype)
