@@ -4,7 +4,8 @@ C2 (1M triangles, 1080p) and C3 (10M triangles, 16 meshes, 32 lights, 4K — the
 small enough for the oracle (seconds with host threads), so they get the full parity check; on top,
 size-independent properties: rendering twice gives the same bits, the union of a sort-first partition
 equals the single frame, and permuting the draw order changes triangle ids but neither coverage nor
-depth.  C4/C5 (50M / 100M triangles) run through properties only.
+depth.  C4/C5 (50M / 100M triangles) run through the same properties and then, since the threaded oracle
+finishes them in well under a minute on the GPU box's host cores, through the full comparison as well.
 """
 import os
 
@@ -106,3 +107,12 @@ def test_c4_c5_properties(make):
         acc[own] = img[own]
         seen += own
     assert (seen == 1).all() and (acc == first[3]).all()
+    # and the oracle on the whole frame: coverage, winning triangle, depth bits exact, colour within 1 LSB
+    del vs
+    cpu = oracle_server(s.width, s.height, threads=THREADS)
+    s.populate(cpu)
+    cpu.render()
+    cov_c, ids_c, depth_c, rgba_c = planes(cpu)
+    assert (first[0] == cov_c).all() and (first[1] == ids_c).all() and (first[2] == depth_c).all()
+    diff = np.abs(first[3].astype(int) - rgba_c.astype(int)).max(axis=-1)
+    assert diff.max() <= 1, (diff > 1).sum()
