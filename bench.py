@@ -67,6 +67,7 @@ class FrameDriver:
         self.cam_t = to_cols_array(scene.camera_transform)
         self.cam_args = (fp(self.cam_t), C.c_float(cam.vfov), C.c_float(cam.aspect_ratio), C.c_float(cam.near),
                          C.c_float(cam.far))
+        self.dropped = 0
         self.keep, self.lights, self.instances = [], [], []
         for lid, t, light in scene.lights:
             tt = to_cols_array(t)
@@ -86,8 +87,12 @@ class FrameDriver:
             rc |= api.set_light(ctx, *a)
         for a in self.instances:
             rc |= api.set_mesh_instance(ctx, *a)
-        rc |= api.render(ctx)
         if rc:
+            raise RuntimeError("frame state failed: " + (api.last_error(ctx) or b"").decode())
+        rc = api.render(ctx)
+        if rc == -7:        # RND_ERR_TRUNCATED: notice that an earlier frame was dropped (streams grew); this frame is enqueued
+            self.dropped += 1
+        elif rc:
             raise RuntimeError("frame failed: " + (api.last_error(ctx) or b"").decode())
 
 

@@ -38,7 +38,10 @@ typedef enum rnd_status {
     RND_ERR_DEVICE = -3,       /* HIP error; maps to wgpu::SurfaceError::Lost on the Rust side */
     RND_ERR_OOM = -4,          /* allocation failed; maps to wgpu::SurfaceError::OutOfMemory */
     RND_ERR_UNSUPPORTED = -5,  /* setting exists in the reference but is not built yet */
-    RND_ERR_NO_FRAME = -6      /* read-back before the first rnd_render */
+    RND_ERR_NO_FRAME = -6,     /* read-back before the first rnd_render */
+    RND_ERR_TRUNCATED = -7     /* from rnd_render only, and only as a notice: an EARLIER frame overflowed an internal
+                                * stream and was therefore not presented (its image buffer kept the frame before it);
+                                * the streams have been grown and the frame of this call HAS been enqueued normally */
 } rnd_status;
 
 #define RND_NONE 0xFFFFFFFFu
@@ -209,7 +212,13 @@ int rnd_read_overlay_rgba8(rnd_ctx* ctx, uint8_t* dst);
 
 /* ---- frame ------------------------------------------------------------------------- */
 /* reference: VisualServer::render :224-311 (+ Pipeline3d::render, Backend::render).
- * Enqueues the whole frame on the context's stream and returns; rnd_finish waits for it. */
+ * Enqueues the whole frame on the context's stream and returns; rnd_finish waits for it.
+ * Internal streams (setup records, clip queue, bin entries) are sized from the scene and grow on demand.  A frame
+ * that overflows one is never shown with triangles missing: its shading kernel writes nothing (the image buffer keeps
+ * the previous frame), the library learns of it without synchronizing (a report in mapped pinned memory, looked at
+ * when the next frame is enqueued), grows the stream, and the next rnd_render returns RND_ERR_TRUNCATED once as a
+ * notice — that call's frame is enqueued as usual.  rnd_finish (and every read-back) re-runs an overflowed frame
+ * until it is complete, so what they return is always a whole frame. */
 int rnd_render(rnd_ctx* ctx);
 int rnd_finish(rnd_ctx* ctx);
 /* The frame of rnd_render for callers that cannot allocate (code under HIP graph capture, tight serving loops,

@@ -17,6 +17,7 @@ pub const RND_ERR_DEVICE: c_int = -3; // -> wgpu::SurfaceError::Lost
 pub const RND_ERR_OOM: c_int = -4; // -> wgpu::SurfaceError::OutOfMemory
 pub const RND_ERR_UNSUPPORTED: c_int = -5;
 pub const RND_ERR_NO_FRAME: c_int = -6;
+pub const RND_ERR_TRUNCATED: c_int = -7; // notice from rnd_render: an earlier frame was dropped, this one is enqueued
 
 /// Layout-identical to `renderer::Vertex` (src/renderer/vertex.rs:3-9).
 #[repr(C)]

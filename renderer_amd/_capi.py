@@ -17,6 +17,7 @@ STATUS = {
     -4: "RND_ERR_OOM",
     -5: "RND_ERR_UNSUPPORTED",
     -6: "RND_ERR_NO_FRAME",
+    -7: "RND_ERR_TRUNCATED",
 }
 
 

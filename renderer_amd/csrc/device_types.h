@@ -189,6 +189,16 @@ struct FrameCounters {
     uint32_t pad[3];
 };
 
+// What the frame's shading kernel reports to the host through mapped pinned memory, so that the host learns of an
+// overflow without synchronizing: OR / maximum over the counter sets of the frame's passes.  `frame_tag` is
+// written last (after a system-scope fence); a report belongs to the frame whose tag it carries.
+struct FrameReport {
+    uint32_t overflow, n_records, n_clip, n_entries;
+    uint32_t pad[3];
+    uint32_t frame_tag;
+};
+static_assert(sizeof(FrameReport) == 32, "FrameReport layout");
+
 struct Capacities {
     uint32_t records;       // slots in the record stream: setup_slots + room for the clipper's records
     uint32_t clip_queue, entries;

@@ -41,6 +41,14 @@ struct FrameBuffers {
     uint32_t* tile_cursor;          // per tile, fill cursor of the multi-tile records
     uint32_t* entries;              // bin entries: record slots, grouped by tile
     FrameCounters* counters;
+    // the counter sets of all passes of the frame (shadow cascades, main pass, MSAA samples), read by the shading
+    // kernel: a frame whose geometry overflowed an internal stream is not presented (the image keeps the previous
+    // frame) and the host is told through `report`
+    const FrameCounters* all_counters;
+    uint32_t n_counter_sets;
+    uint32_t report_tag;
+    uint64_t ran_mask;              // bit s: counter set s was written this frame (sets beyond 63: assumed)
+    FrameReport* report;            // mapped pinned host memory (may be null)
     // pixel stage
     const TileRef* launch_order;    // owned tiles in launch order (XCD-aware)
     uint32_t n_owned;

@@ -1588,6 +1588,24 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(
     const uint32_t part = (blockIdx.x / fb.n_owned) * (256u * PPT);     // first tile-local pixel of this workgroup
     const uint32_t tile_x0 = (ref.tile % fc.tiles_x) * kTile, tile_y0 = (ref.tile / fc.tiles_x) * kTile;
     const unsigned long long* vis0 = reinterpret_cast<const unsigned long long*>(fb.vis) + (size_t)ref.tile * kTilePixels;
+    // A frame whose geometry phase overflowed an internal stream (records, clip queue, bin entries: triangles were
+    // dropped) is not presented: nothing is written, the image keeps the previous frame.  The host learns of it
+    // from the report (no synchronization) and has grown the streams by the next frame; rnd_finish re-runs it.
+    {
+        uint32_t ovf = 0, n_rec = 0, n_clip = 0, n_ent = 0;
+        for (uint32_t s = 0; s < fb.n_counter_sets; ++s) {          // wave-uniform: scalar loads
+            if (s < 64u && !((fb.ran_mask >> s) & 1ull)) continue;
+            const FrameCounters& c = fb.all_counters[s];
+            ovf |= c.overflow; n_rec = max(n_rec, c.n_records); n_clip = max(n_clip, c.n_clip); n_ent = max(n_ent, c.n_entries);
+        }
+        if (blockIdx.x == 0 && tid == 0 && fb.report) {
+            volatile FrameReport* r = fb.report;
+            r->overflow = ovf; r->n_records = n_rec; r->n_clip = n_clip; r->n_entries = n_ent;
+            __threadfence_system();
+            r->frame_tag = fb.report_tag;
+        }
+        if (ovf & 7u) return;          // (uniform over the grid; before any barrier)
+    }
     __syncthreads();
 
     PixelInputs px[PPT];

@@ -89,6 +89,10 @@ VisualServer::VisualServer(uint32_t width, uint32_t height, int device) : device
         HIP_CHECK(hipHostGetDevicePointer(&st.host_dev, st.host, 0));
         st.bytes = kStagingBytes;
     }
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_reports_), kReportSlots * sizeof(FrameReport), hipHostMallocMapped | hipHostMallocPortable));
+    std::memset(h_reports_, 0, kReportSlots * sizeof(FrameReport));
+    HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_reports_), h_reports_, 0));
+    if (const char* e = std::getenv("RND_TEST_SMALL_STREAMS")) test_small_streams_ = std::atoi(e) != 0;
     d_counters_[0].ensure(1); d_counters_[1].ensure(1);
     HIP_CHECK(hipStreamCreateWithFlags(&geo_stream_, hipStreamNonBlocking));     // (a higher or lower stream priority changes nothing measurable)
     for (int k = 0; k < 2; ++k) {
@@ -145,6 +149,7 @@ VisualServer::~VisualServer() {
         if (s.done) (void)hipEventDestroy(s.done);
     }
     if (h_counters_) (void)hipHostFree(h_counters_);
+    if (h_reports_) (void)hipHostFree(h_reports_);
     for (auto& es : event_sets_)
         for (auto& e : es.ev) if (e) (void)hipEventDestroy(e);
     if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
@@ -689,6 +694,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     auto t_start = now(); auto t_prev = t_start;
     auto lap = [&](int k) { if (prof) { auto t = now(); acc[k] += std::chrono::duration<double, std::micro>(t - t_prev).count(); t_prev = t; } };
     use_device();
+    poll_reports();                     // overflow reports of the frames in flight (no wait): streams grow before this frame is laid out
     if (scaled()) want_hdr = true;      // the present pass samples the HDR target
     const uint32_t p = parity_ ^ 1u;    // this frame's copy of the buffers that geometry writes and shading reads
     // Overlap pays when there is shading to hide the geometry chain behind: the hand-over between the two
@@ -756,10 +762,13 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
 
     // capacities
     cap_.setup_slots = fc.n_units * fc.chunk_tris;
-    clip_records_ = std::max<uint32_t>(clip_records_, fc.n_tris / 8 + 4096);
+    // (RND_TEST_SMALL_STREAMS: floors so small that ordinary test scenes overflow them, for the tests of that path)
+    const uint32_t floor_clip_records = test_small_streams_ ? 8u : fc.n_tris / 8 + 4096;
+    const uint32_t floor_clip_queue = test_small_streams_ ? 16u : std::max<uint32_t>(fc.n_tris / 8, 65536);
+    clip_records_ = std::max<uint32_t>(clip_records_, floor_clip_records);
     cap_.records = (uint32_t)std::min<uint64_t>((uint64_t)cap_.setup_slots + clip_records_, 0xFFFFFFF0ull);
-    if (cap_.clip_queue < std::max<uint32_t>(fc.n_tris / 8, 65536)) cap_.clip_queue = std::max<uint32_t>(fc.n_tris / 8, 65536);
-    const uint64_t want_entries = std::max<uint64_t>(4ull * cap_.records + 16ull * n_tiles, 1u << 20);
+    if (cap_.clip_queue < floor_clip_queue) cap_.clip_queue = floor_clip_queue;
+    const uint64_t want_entries = test_small_streams_ ? 64u : std::max<uint64_t>(4ull * cap_.records + 16ull * n_tiles, 1u << 20);
     if (cap_.entries < want_entries) cap_.entries = (uint32_t)std::min<uint64_t>(want_entries, 0xFFFFFFF0ull);
     // the per-frame intermediate streams: hipMalloc'ed buffers that grow on demand, or — for the no-allocation
     // frame — slices of the static scratch array
@@ -911,6 +920,15 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     fb.vis_stride = (uint64_t)tiles_x_ * tiles_y_ * kTilePixels;
     fb.frame_rgba8 = (world_ > 1 || scaled()) ? nullptr : (noalloc ? noalloc_out : d_frame_.ptr);
     fb.tiles_rgba8 = world_ > 1 ? (noalloc ? noalloc_out : ext_tiles_ ? ext_tiles_ : d_tiles_.ptr) : nullptr;
+    fb.all_counters = bp.counters; fb.n_counter_sets = n_counter_sets;
+    fb.ran_mask = ~0ull; fb.report = nullptr; fb.report_tag = 0;
+    if (!use_graphs_) {         // (a replayed graph would carry a stale tag: finish() alone watches such frames)
+        const uint32_t slot = report_next_;
+        report_next_ = (report_next_ + 1) % kReportSlots;
+        report_tag_ = report_tag_ + 1u ? report_tag_ + 1u : 1u;
+        report_expect_[slot] = report_tag_;
+        fb.report = d_reports_ + slot; fb.report_tag = report_tag_;
+    }
     last_noalloc_ = noalloc; last_counters_ = bp.counters; last_vis_ = bp.vis; pending_want_hdr_ = want_hdr;
     last_frame_out_ = noalloc && world_ <= 1 ? noalloc_out : d_frame_.ptr;
     last_tiles_out_ = fb.tiles_rgba8;
@@ -1012,6 +1030,11 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     if (overlap_) HIP_CHECK(hipEventRecord(geo_done_[p], gs));
     if (overlap) HIP_CHECK(hipStreamWaitEvent(stream_, geo_done_[p], 0));
     mark(8, stream_);       // shading starts here on its own stream (the hand-over from the geometry stream takes a few us)
+    {
+        uint64_t ran = 0;
+        for (uint32_t k = 0; k < n_counter_sets_ && k < 64u; ++k) if (counter_set_ran_[k]) ran |= 1ull << k;
+        fb.ran_mask = ran;
+    }
     launch_shade(fb, fc, stream_);
     if (scaled())   // show_texture.wgsl over the surface (visual_server.rs:629-633: filtered sampler above factor 1)
         launch_present(d_hdr_.ptr, width_, height_, d_present_.ptr, surface_w_, surface_h_, render_size_factor_ > 1.0f, tone_mapping_, stream_);
@@ -1112,7 +1135,36 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     stats_.n_pixels = 0;
 }
 
-void VisualServer::render() { enqueue_frame(false); }
+// reference: VisualServer::render (visual_server.rs:224-311).  The notice about an earlier truncated frame is
+// raised AFTER this call's frame has been enqueued (see rnd.h).
+void VisualServer::render() {
+    enqueue_frame(false);
+    if (truncated_notice_) {
+        truncated_notice_ = false;
+        throw Error(RND_ERR_TRUNCATED, "an earlier frame overflowed an internal stream and was not presented; the streams have been grown and this frame is enqueued");
+    }
+}
+
+void VisualServer::grow_streams(uint32_t overflow, uint32_t n_records, uint32_t n_clip, uint32_t n_entries) {
+    if (overflow & 1u) clip_records_ = std::max<uint32_t>(clip_records_, (uint32_t)std::min<uint64_t>((uint64_t)n_records + n_records / 4 + 4096, 0x7FFFFFF0ull));
+    if (overflow & 2u) cap_.clip_queue = std::max<uint32_t>(cap_.clip_queue, (uint32_t)std::min<uint64_t>((uint64_t)n_clip + n_clip / 4 + 4096, 0xFFFFFFF0ull));
+    if (overflow & 4u) cap_.entries = std::max<uint32_t>(cap_.entries, (uint32_t)std::min<uint64_t>((uint64_t)n_entries + n_entries / 4 + 4096, 0xFFFFFFF0ull));
+}
+
+// Looks at the reports of the frames in flight without waiting for any: a report whose tag has arrived belongs to
+// a frame whose shading kernel has started; if its geometry overflowed, the streams grow to what it asked for.
+void VisualServer::poll_reports() {
+    for (uint32_t s = 0; s < kReportSlots; ++s) {
+        if (!report_expect_[s]) continue;
+        const volatile FrameReport* r = &h_reports_[s];
+        if (r->frame_tag != report_expect_[s]) continue;       // not there yet
+        report_expect_[s] = 0;
+        const uint32_t ovf = r->overflow & 7u;
+        if (!ovf) continue;
+        grow_streams(ovf, r->n_records, r->n_clip, r->n_entries);
+        truncated_notice_ = true;
+    }
+}
 
 // rnd_render_noalloc: the same frame with every intermediate stream in the static scratch array and the image in
 // the caller's buffer.  No hipMalloc/hipFree/hipHostMalloc on this path (pinned blocks and events date from the
@@ -1146,9 +1198,7 @@ void VisualServer::finish() {
         }
         if (!c.overflow) break;
         // an internal stream was too small: grow it to what the frame asked for and run it again
-        if (c.overflow & 1u) clip_records_ = (uint32_t)std::min<uint64_t>((uint64_t)c.n_records + c.n_records / 4 + 4096, 0x7FFFFFF0ull);
-        if (c.overflow & 2u) cap_.clip_queue = (uint32_t)std::min<uint64_t>((uint64_t)c.n_clip + c.n_clip / 4 + 4096, 0xFFFFFFF0ull);
-        if (c.overflow & 4u) cap_.entries = (uint32_t)std::min<uint64_t>((uint64_t)c.n_entries + c.n_entries / 4 + 4096, 0xFFFFFFF0ull);
+        grow_streams(c.overflow, c.n_records, c.n_clip, c.n_entries);
         grew = 1;
         if (last_noalloc_) {
             // growing means allocating: the frame in the caller's buffer is incomplete and stays so; the next

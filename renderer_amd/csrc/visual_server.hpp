@@ -287,6 +287,17 @@ private:
     const uint8_t* last_frame_out_ = nullptr;
     std::vector<uint8_t> counter_set_ran_;    // per counter set of the last frame: its pass ran (a skipped cascade leaves its slot unwritten)
     bool pending_want_hdr_ = false;           // the frame finish() may have to run again wanted the HDR plane
+    // Overflow reports of the frames in flight (FrameReport in mapped pinned memory, written by each frame's shading
+    // kernel): looked at without synchronizing when the next frame is enqueued.
+    static constexpr uint32_t kReportSlots = 8;
+    FrameReport* h_reports_ = nullptr;        // pinned, mapped
+    FrameReport* d_reports_ = nullptr;        // the same block as the device addresses it
+    uint32_t report_expect_[kReportSlots] = {};   // tag each slot is waiting for (0: none)
+    uint32_t report_next_ = 0, report_tag_ = 0;
+    bool truncated_notice_ = false;           // a frame in flight was found truncated: the next render() says so once
+    bool test_small_streams_ = false;         // RND_TEST_SMALL_STREAMS=1: start with tiny streams (overflow tests)
+    void poll_reports();
+    void grow_streams(uint32_t overflow, uint32_t n_records, uint32_t n_clip, uint32_t n_entries);
     const uint8_t* last_tiles_out_ = nullptr;
     // the per-frame host tables, kept between frames so that a steady state allocates nothing on the host either
     std::vector<DrawItem> items_, shadow_items_;

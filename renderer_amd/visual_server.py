@@ -266,8 +266,14 @@ class VisualServer:
 
     # -- frame ---------------------------------------------------------------------------
     def render(self):
-        """visual_server.rs:224-311 — enqueues the frame; read-backs wait for it."""
-        self._check(self.api.render(self._ctx))
+        """visual_server.rs:224-311 — enqueues the frame; read-backs wait for it.  Returns False when the library
+        gives notice (RND_ERR_TRUNCATED) that an earlier frame overflowed an internal stream and was not presented;
+        this call's frame is enqueued either way."""
+        rc = self.api.render(self._ctx)
+        if rc == -7:
+            return False
+        self._check(rc)
+        return True
 
     def finish(self):
         self._check(self.api.finish(self._ctx))
