@@ -25,6 +25,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
+N_SIMDS, VALU_CLOCK_HZ = 256 * 4, 2.4e9      # a wave64 VALU instruction occupies one 16-lane SIMD for 4 cycles
+TIMED_FRAMES = 16          # frames with events around every kernel, after the throughput loop (outside `elapsed`)
 
 WORKLOADS = {
     # name -> (scene builder name, description)
@@ -101,8 +103,9 @@ def algorithmic_bytes(stats, n_visible_tris):
     nv, nt = stats["n_vertices"], stats["n_triangles"]
     nrec, nbin, p = stats["n_setup"], stats["n_bin_entries"], stats["n_pixels"]
     return {
-        # SoA positions in, clip xyzw and the snapped vertex (x, y, z/w, outcodes) out; + the visibility clear timed with it
-        "transform": 12 * nv + 16 * nv + 16 * nv + 8 * p,
+        "clear": 8 * p,                                        # visibility words of the owned tiles
+        # SoA positions in, clip xyzw and the snapped vertex (x, y, z/w, outcodes) out
+        "transform": 12 * nv + 16 * nv + 16 * nv,
         # indices, each snapped vertex once, one 8-byte visibility word per pixel (direct small-triangle
         # path), and for the triangles that go through the bins a 48-byte record + (tile word, bin pos)
         "setup": 12 * nt + 16 * nv + 8 * p + 56 * min(nbin, nrec),
@@ -224,7 +227,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    mean, n_frames = vs.mean_timings()
+    # per-kernel durations: TIMED_FRAMES more frames of the same workload, each with HIP events around every
+    # kernel (on the streams the kernels are launched on) and without the overlap with its neighbours
+    vs.timing_stats(reset=True)
+    vs.time_frames(TIMED_FRAMES)
+    for _ in range(TIMED_FRAMES):
+        step()
+    fence()
+    mean, worst, n_frames = vs.timing_stats()
     stats = vs.frame_stats()
     n_tris = scene.n_triangles
     ms_per_step = elapsed / args.steps * 1e3
@@ -237,22 +247,32 @@ def main():
             raise SystemExit("bench frame is empty: refusing to report a number")
         alg = algorithmic_bytes(stats, n_visible)
         kernels = {}
-        for k in ("transform", "setup", "bin", "raster", "shade"):
+        for k in ("clear", "transform", "setup", "bin", "raster", "shade"):
             ms = mean[k + "_ms"]
-            kernels[k] = {"ms": round(ms, 5), "alg_bytes": int(alg[k]),
+            kernels[k] = {"ms": round(ms, 5), "ms_max": round(worst[k + "_ms"], 5), "alg_bytes": int(alg[k]),
                           "gbps": round(alg[k] / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
-        kernels["scan"] = {"ms": round(mean["scan_ms"], 5)}
+        for k in ("cull", "clip", "scan"):
+            kernels[k] = {"ms": round(mean[k + "_ms"], 5), "ms_max": round(worst[k + "_ms"], 5)}
         dominant = max(("transform", "setup", "bin", "raster", "shade"), key=lambda k: mean[k + "_ms"])
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes per launch from rocprofv3 PMC passes
+        tj = {}
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes and VALU instructions per launch from rocprofv3 PMC passes
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("workload") == args.workload and tj.get("n_gpus", 1) == world:
-                    traffic = tj.get("kernels", {}).get(dominant)
+                if tj.get("workload") != args.workload or tj.get("n_gpus", 1) != world:
+                    tj = {}
             except Exception:
-                traffic = None
-        achieved = kernels[dominant]["gbps"]
+                tj = {}
+
+        def roofline_of(k):
+            ach = kernels[k]["gbps"]
+            r = {"bound": "hbm", "kernel": k, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(ach / HBM_PEAK_GBS, 4) if ach else None, "traffic": tj.get("kernels", {}).get(k)}
+            insts = tj.get("valu_insts", {}).get(k)
+            if insts and mean[k + "_ms"] > 0:
+                # what actually bounds these kernels: share of the SIMDs' issue cycles spent on VALU instructions
+                r["valu_busy"] = round(insts * 4 / (N_SIMDS * VALU_CLOCK_HZ * mean[k + "_ms"] * 1e-3), 3)
+            return r
         result = {
             "metric": "Mtriangles/s", "value": round(n_tris * fps / 1e6, 2), "unit": "Mtriangles/s",
             "frames_per_s": round(fps, 2),
@@ -263,9 +283,13 @@ def main():
                        "triangles": n_tris, "width": scene.width, "height": scene.height,
                        "lights": len(scene.lights), "draw_items": stats["n_draw_items"],
                        "partition": "single GPU" if world == 1 else f"sort-first screen tiles over {world} GPUs, RCCL gather to rank 0"},
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic},
+            "roofline": roofline_of(dominant),
+            # north_star asks for raster AND shade: at this triangle density the raster is the direct
+            # small-triangle path inside k_setup (k_raster has no bin entries), so that kernel is reported too
+            "roofline_setup": roofline_of("setup"),
+            "roofline_raster": roofline_of("raster"),
             "kernels": kernels,
+            "dropped_frames": driver.dropped,
             "gpu_frame_ms": round(mean["frame_ms"], 4), "timed_frames": n_frames,
             "frame_stats": stats,
         }

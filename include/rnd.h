@@ -71,16 +71,20 @@ enum { RND_LIGHT_DIRECTIONAL = 0, RND_LIGHT_POINT = 1 };
 /* reference: BillboardMode, src/material.rs:21-25 / visual_server.rs:716-720 */
 enum { RND_BILLBOARD_OFF = 0, RND_BILLBOARD_ON = 1, RND_BILLBOARD_FIXED_SIZE = 2 };
 
-/* Per-frame kernel timings (HIP events on the context's stream), milliseconds. */
+/* Per-frame kernel timings, milliseconds: HIP events recorded on the streams the kernels are launched on, one
+ * before and one after each kernel of the main pass. */
 typedef struct rnd_timings {
-    float transform_ms;   /* K1 vertex transform */
-    float setup_ms;       /* K2a triangle setup + cull + clip + tile count */
+    float transform_ms;   /* K1 vertex transform (k_transform alone) */
+    float setup_ms;       /* K2a triangle setup, incl. the direct small-triangle raster (k_setup alone) */
     float scan_ms;        /* tile offset scan */
     float bin_ms;         /* K2b bin fill */
-    float raster_ms;      /* K3 per-tile raster */
-    float shade_ms;       /* K4 deferred shade + tone map */
+    float raster_ms;      /* K3 per-tile raster (+ the further MSAA samples' geometry passes) */
+    float shade_ms;       /* K4 deferred shade + tone map (+ present / 2D overlay when they run) */
     float frame_ms;       /* first kernel start -> last kernel end */
     float shadow_ms;      /* shadow-cascade depth passes (directional lights) */
+    float clear_ms;       /* visibility clear + table upload (k_clear) */
+    float cull_ms;        /* work-unit culling (k_cull) */
+    float clip_ms;        /* K2c clipper (k_clip) */
 } rnd_timings;
 
 /* Per-frame counters used to state algorithmic bytes. */
@@ -257,6 +261,11 @@ int rnd_last_timings(rnd_ctx* ctx, rnd_timings* out);
  * the context's stream around each kernel; harvested without stalling the frames in flight).
  * Waits for the frames still in flight.  reset != 0 clears the accumulators afterwards. */
 int rnd_mean_timings(rnd_ctx* ctx, rnd_timings* mean, uint32_t* n_frames, int reset);
+/* Timing events are normally recorded on a sample of the frames only (every 16th: a timed frame runs without the
+ * overlap with its neighbours, so that its kernel durations are its own).  rnd_time_frames makes the next n frames
+ * timed ones; rnd_timing_stats is rnd_mean_timings with the per-kernel maximum beside the mean (either may be NULL). */
+int rnd_time_frames(rnd_ctx* ctx, uint32_t n);
+int rnd_timing_stats(rnd_ctx* ctx, rnd_timings* mean, rnd_timings* max, uint32_t* n_frames, int reset);
 int rnd_frame_stats_get(rnd_ctx* ctx, rnd_frame_stats* out);
 
 /* ---- multi-GPU (no counterpart in the reference, which is single-device;

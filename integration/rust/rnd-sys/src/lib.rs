@@ -57,6 +57,9 @@ pub struct rnd_timings {
     pub shade_ms: f32,
     pub frame_ms: f32,
     pub shadow_ms: f32,
+    pub clear_ms: f32,
+    pub cull_ms: f32,
+    pub clip_ms: f32,
 }
 
 #[repr(C)]
@@ -111,6 +114,8 @@ extern "C" {
     pub fn rnd_read_triangle_ids(ctx: *mut rnd_ctx, dst: *mut u32) -> c_int;
     pub fn rnd_last_timings(ctx: *mut rnd_ctx, out: *mut rnd_timings) -> c_int;
     pub fn rnd_mean_timings(ctx: *mut rnd_ctx, mean: *mut rnd_timings, n_frames: *mut u32, reset: c_int) -> c_int;
+    pub fn rnd_time_frames(ctx: *mut rnd_ctx, n: u32) -> c_int;
+    pub fn rnd_timing_stats(ctx: *mut rnd_ctx, mean: *mut rnd_timings, max: *mut rnd_timings, n_frames: *mut u32, reset: c_int) -> c_int;
     pub fn rnd_frame_stats_get(ctx: *mut rnd_ctx, out: *mut rnd_frame_stats) -> c_int;
 
     pub fn rnd_set_tile_partition(ctx: *mut rnd_ctx, rank: u32, world: u32) -> c_int;

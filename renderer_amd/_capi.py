@@ -45,7 +45,7 @@ class SubmeshDesc(C.Structure):
 class Timings(C.Structure):
     _fields_ = [(n, C.c_float) for n in (
         "transform_ms", "setup_ms", "scan_ms", "bin_ms", "raster_ms", "shade_ms", "frame_ms",
-        "shadow_ms")]
+        "shadow_ms", "clear_ms", "cull_ms", "clip_ms")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -113,6 +113,8 @@ SIGNATURES = {
     "read_triangle_ids": (C.c_int, [_P, _P]),
     "last_timings": (C.c_int, [_P, C.POINTER(Timings)]),
     "mean_timings": (C.c_int, [_P, C.POINTER(Timings), C.POINTER(C.c_uint32), C.c_int]),
+    "time_frames": (C.c_int, [_P, C.c_uint32]),
+    "timing_stats": (C.c_int, [_P, C.POINTER(Timings), C.POINTER(Timings), C.POINTER(C.c_uint32), C.c_int]),
     "frame_stats_get": (C.c_int, [_P, C.POINTER(FrameStats)]),
     "set_tile_partition": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "tile_info": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
@@ -127,7 +129,7 @@ SIGNATURES = {
 }
 
 # entry points that only make sense with device memory; a host-only library may omit them
-DEVICE_ONLY = {"mean_timings", "render_noalloc", "set_tiles_output", "tiles_device_ptr", "detile", "detile_gathered", "packed_device_ptr", "unpack", "set_stream",
+DEVICE_ONLY = {"mean_timings", "render_noalloc", "time_frames", "timing_stats", "set_tiles_output", "tiles_device_ptr", "detile", "detile_gathered", "packed_device_ptr", "unpack", "set_stream",
                "color_device_ptr"}
 
 

@@ -191,6 +191,16 @@ int rnd_mean_timings(rnd_ctx* ctx, rnd_timings* mean, uint32_t* n_frames, int re
     REQUIRE(ctx, mean && n_frames, "null output");
     return guard(ctx, [&](rnd::VisualServer& v) { *mean = v.mean_timings(*n_frames, reset != 0); });
 }
+int rnd_time_frames(rnd_ctx* ctx, uint32_t n) { return guard(ctx, [&](rnd::VisualServer& v) { v.time_frames(n); }); }
+int rnd_timing_stats(rnd_ctx* ctx, rnd_timings* mean, rnd_timings* max, uint32_t* n_frames, int reset) {
+    REQUIRE(ctx, n_frames, "null output");
+    return guard(ctx, [&](rnd::VisualServer& v) {
+        rnd_timings mx{};
+        const rnd_timings m = v.mean_timings(*n_frames, reset != 0, &mx);
+        if (mean) *mean = m;
+        if (max) *max = mx;
+    });
+}
 int rnd_frame_stats_get(rnd_ctx* ctx, rnd_frame_stats* out) {
     REQUIRE(ctx, out, "null output");
     return guard(ctx, [&](rnd::VisualServer& v) { *out = v.frame_stats(); });

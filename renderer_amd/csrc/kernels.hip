@@ -1011,6 +1011,7 @@ constexpr uint32_t kBinClipBlocks = 64;
 __global__ __launch_bounds__(256) void k_bin_fill(FrameBuffers fb, Capacities cap) {
     FrameConstRef fc = frame_const_ref(fb.frame_const);
     const uint32_t n_chunks = fc.n_units;
+    if (fb.counters->n_entries == 0u) return;        // nothing was counted into any bin
     if (blockIdx.x < n_chunks) {
         if (blockIdx.x >= fb.counters->n_active) return;
         const uint32_t base = blockIdx.x * fc.chunk_tris;
@@ -1107,6 +1108,9 @@ __global__ __launch_bounds__(256) void k_raster(FrameBuffers fb, Capacities cap)
 #endif
     constexpr uint32_t kMediumLanes = RND_MEDIUM_LANES;
     const uint32_t tid = threadIdx.x;
+    // a pass without bin entries and without wide records (C3: every triangle took the direct path in k_setup) has
+    // nothing here: one scalar load decides it for all ten thousand workgroups
+    if (fb.counters->n_entries == 0u && fb.counters->n_wide == 0u) return;
     // workgroups [0, n_owned) are the tiles' own; the ones behind them take the (tile, slice) work items
     // k_scan_tiles listed for heavy tiles, whose candidates are dealt to the slices batch by batch
     uint32_t tile, slice = 0;
@@ -2035,7 +2039,7 @@ void launch_setup(const FrameBuffers& fb, const FrameConst& fc, const Capacities
 }
 void launch_clip(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {
     if (!fc.n_tris) return;
-    uint32_t blocks = min(div_up(cap.clip_queue, 256), 1024u);
+    uint32_t blocks = min(div_up(cap.clip_queue, 256), 256u);       // grid-stride over the queue; it is empty in most frames
     hipLaunchKernelGGL(k_clip, dim3(blocks), dim3(256), 0, stream, fb, cap);
 }
 void launch_scan(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {

@@ -937,7 +937,8 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
 
     // per-kernel timing events on a sample of the frames (every kTimingStride-th, and the first few):
     // eight event records per frame are a noticeable share of the host's enqueue time
-    const bool timed = frame_counter_ < 4 || frame_counter_ % (use_graphs_ ? 4 * kTimingStride : kTimingStride) == 0;
+    const bool timed = force_timed_ > 0 || frame_counter_ < 4 || frame_counter_ % (use_graphs_ ? 4 * kTimingStride : kTimingStride) == 0;
+    if (force_timed_) --force_timed_;
     ++frame_counter_;
     hipEvent_t* ev_ = nullptr;
     EventSet* timed_set = nullptr;
@@ -998,10 +999,13 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     mark(0, gs);
     counter_set_ran_[0] = 1;
     clear(fb, fc);                      // visibility words, tile counts, vertex-block flags, frame counters
+    mark(9, gs);
     launch_cull(fb, fc, gs);       // work units that can reach the view volume and this context's stripes
+    mark(10, gs);
     launch_transform(fb, fc, gs);
     mark(1, gs);
     launch_setup(fb, fc, cap_, gs);
+    mark(11, gs);
     launch_clip(fb, fc, cap_, gs);
     mark(2, gs);
     launch_scan(fb, fc, cap_, gs);
@@ -1227,34 +1231,31 @@ void VisualServer::finish() {
 // Reads one completed frame's events into timings_ and the running sums.
 void VisualServer::harvest(EventSet& es) {
     HIP_CHECK(hipEventSynchronize(es.ev[6]));
-    float ms[6] = {};
-    for (int k = 0; k < 6; ++k) HIP_CHECK(hipEventElapsedTime(&ms[k], es.ev[k], es.ev[k + 1]));
-    HIP_CHECK(hipEventElapsedTime(&ms[5], es.ev[8], es.ev[6]));
+    auto span = [&](int from, int to) { float ms = 0.0f; HIP_CHECK(hipEventElapsedTime(&ms, es.ev[from], es.ev[to])); return ms; };
     timings_ = rnd_timings{};
-    timings_.transform_ms = ms[0]; timings_.setup_ms = ms[1]; timings_.scan_ms = ms[2]; timings_.bin_ms = ms[3];
-    timings_.raster_ms = ms[4]; timings_.shade_ms = ms[5];
-    HIP_CHECK(hipEventElapsedTime(&timings_.shadow_ms, es.ev[7], es.ev[0]));
-    HIP_CHECK(hipEventElapsedTime(&timings_.frame_ms, es.ev[7], es.ev[6]));
-    timing_sum_[7] += timings_.shadow_ms;
-    for (int k = 0; k < 6; ++k) timing_sum_[k] += ms[k];
-    timing_sum_[6] += timings_.frame_ms;
+    timings_.clear_ms = span(0, 9); timings_.cull_ms = span(9, 10); timings_.transform_ms = span(10, 1);
+    timings_.setup_ms = span(1, 11); timings_.clip_ms = span(11, 2); timings_.scan_ms = span(2, 3);
+    timings_.bin_ms = span(3, 4); timings_.raster_ms = span(4, 5); timings_.shade_ms = span(8, 6);
+    timings_.shadow_ms = span(7, 0); timings_.frame_ms = span(7, 6);
+    const float* f = reinterpret_cast<const float*>(&timings_);
+    for (int k = 0; k < kTimingFields; ++k) { timing_sum_[k] += f[k]; timing_max_[k] = std::max(timing_max_[k], f[k]); }
     timing_frames_ += 1;
     have_timings_ = true;
     es.pending = false;
 }
 
-rnd_timings VisualServer::mean_timings(uint32_t& n_frames, bool reset) {
+rnd_timings VisualServer::mean_timings(uint32_t& n_frames, bool reset, rnd_timings* max_out) {
     finish();
-    rnd_timings m{};
+    rnd_timings m{}, mx{};
     n_frames = timing_frames_;
     if (timing_frames_) {
         const double inv = 1.0 / timing_frames_;
-        m.transform_ms = (float)(timing_sum_[0] * inv); m.setup_ms = (float)(timing_sum_[1] * inv);
-        m.scan_ms = (float)(timing_sum_[2] * inv); m.bin_ms = (float)(timing_sum_[3] * inv);
-        m.raster_ms = (float)(timing_sum_[4] * inv); m.shade_ms = (float)(timing_sum_[5] * inv);
-        m.frame_ms = (float)(timing_sum_[6] * inv); m.shadow_ms = (float)(timing_sum_[7] * inv);
+        float* f = reinterpret_cast<float*>(&m);
+        float* g = reinterpret_cast<float*>(&mx);
+        for (int k = 0; k < kTimingFields; ++k) { f[k] = (float)(timing_sum_[k] * inv); g[k] = timing_max_[k]; }
     }
-    if (reset) { for (double& v : timing_sum_) v = 0.0; timing_frames_ = 0; }
+    if (max_out) *max_out = mx;
+    if (reset) { for (double& v : timing_sum_) v = 0.0; for (float& v : timing_max_) v = 0.0f; timing_frames_ = 0; }
     return m;
 }
 

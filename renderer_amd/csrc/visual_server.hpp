@@ -130,7 +130,8 @@ public:
     void read_color_hdr(float* dst);
     void read_planes(float* depth, uint32_t* ids, uint8_t* coverage);
     rnd_timings last_timings();
-    rnd_timings mean_timings(uint32_t& n_frames, bool reset);
+    rnd_timings mean_timings(uint32_t& n_frames, bool reset, rnd_timings* max_out = nullptr);
+    void time_frames(uint32_t n) { force_timed_ = n; }
     rnd_frame_stats frame_stats();
 
     // multi-GPU
@@ -176,7 +177,7 @@ private:
     hipStream_t stream_ = nullptr;
     bool own_stream_ = true;
     // ring of per-frame event sets, so kernel timings can be harvested without a per-frame sync
-    static constexpr int kEventSets = 16, kEventsPerSet = 9;      // [7] = before the shadow passes, [8] = before shading
+    static constexpr int kEventSets = 16, kEventsPerSet = 12;     // [7] = before the shadow passes, [8] = before shading, [9..11] after clear / cull / setup
     struct EventSet {
         hipEvent_t ev[kEventsPerSet] = {};
         bool pending = false;
@@ -192,8 +193,11 @@ private:
     bool use_graphs_ = false;     // RND_GRAPH=1 turns them on (no gain measured on ROCm 7.2: hipGraphLaunch costs the host what the launches do)
     uint64_t frame_counter_ = 0;
     int last_set_ = -1;
-    double timing_sum_[8] = {};
+    static constexpr int kTimingFields = sizeof(rnd_timings) / sizeof(float);
+    double timing_sum_[kTimingFields] = {};
+    float timing_max_[kTimingFields] = {};
     uint32_t timing_frames_ = 0;
+    uint32_t force_timed_ = 0;        // rnd_time_frames: this many further frames record timing events
     void harvest(EventSet& s);
     uint8_t* ext_tiles_ = nullptr;
     uint64_t ext_tiles_bytes_ = 0;

@@ -323,6 +323,16 @@ class VisualServer:
         self._check(self.api.mean_timings(self._ctx, C.byref(t), C.byref(n), int(reset)))
         return t.as_dict(), n.value
 
+    def time_frames(self, n):
+        """rnd_time_frames: the next n frames record per-kernel timing events (and run un-overlapped)."""
+        self._check(self.api.time_frames(self._ctx, int(n)))
+
+    def timing_stats(self, reset=False):
+        """(mean, max, n_frames) per kernel over the timed frames since the last reset."""
+        mean, mx, n = Timings(), Timings(), C.c_uint32()
+        self._check(self.api.timing_stats(self._ctx, C.byref(mean), C.byref(mx), C.byref(n), int(reset)))
+        return mean.as_dict(), mx.as_dict(), n.value
+
     def frame_stats(self):
         s = FrameStats()
         self._check(self.api.frame_stats_get(self._ctx, C.byref(s)))
