@@ -7,7 +7,10 @@ A step is one frame: the reference's per-frame call sequence (set_camera, set_li
 set_mesh_instance x M, render — engine.rs:100-165, visual_server.rs:224-311) over a synthetic
 scene whose meshes are already resident in HBM.  With N > 1 the frame is partitioned sort-first by
 screen tiles, one process per GPU, and the finished tiles are gathered to rank 0 over RCCL and
-de-tiled there (strong scaling: the frame is fixed, the tiles are split).
+de-tiled there (strong scaling: the frame is fixed, the tiles are split).  The instanced workload (c5) is
+partitioned sort-last instead: every rank renders its share of the instances at full resolution into a packed
+(depth | rgba8) frame, and the frames are depth-composited by a direct-send exchange (strips all-to-all, local
+minimum, strips to rank 0).
 
 Prints ONE JSON line on rank 0.
 """
@@ -48,6 +51,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--lights", type=int, default=-1, help="keep only the first N lights (debug only)")
+    ap.add_argument("--partition", default="auto", choices=["auto", "sort-first", "sort-last"],
+                    help="how N > 1 GPUs share the frame (auto: sort-last for c5, sort-first otherwise)")
     ap.add_argument("--as-rank", default="", help="R/W: time the share of rank R of a W-way sort-first partition on this one "
                     "GPU, no gather (debug only: per-rank kernel times of the multi-GPU path)")
     return ap.parse_args()
@@ -146,11 +151,20 @@ def main():
         scene.lights = scene.lights[:args.lights]
         desc += f" (first {args.lights} lights only)"
 
+    n_tris = scene.n_triangles
+    sort_last = world > 1 and (args.partition == "sort-last" or (args.partition == "auto" and args.workload == "c5"))
+    if sort_last:
+        scene.instances = scene.instances[rank::world]          # this rank's shard of the instances (meshes are shared)
     vs = VisualServer(scene.width, scene.height, device=local_rank)
     stream = torch.cuda.Stream(device=local_rank)
     vs.set_stream(stream.cuda_stream)
-    gathers, comm = None, None
-    if world > 1:
+    gathers, comm, strips = None, None, None
+    if sort_last:
+        from renderer_amd.sort_first import StripComposite
+        strips = StripComposite(rank, world, scene.width * scene.height, "cuda")
+        comm = torch.cuda.Stream(device=local_rank)
+        ev = {k: [torch.cuda.Event() for _ in range(2)] for k in ("rendered", "exchanged", "reduced", "collected", "unpacked")}
+    elif world > 1:
         # Sort-first: every rank shades the stripes it owns into a tile-major buffer; the buffers
         # are gathered on rank 0 (RCCL send/recv group, one xGMI link per peer) on a second stream
         # while the next frame renders into the other buffer of the pair.
@@ -169,11 +183,49 @@ def main():
     driver = FrameDriver(vs, scene)
     frame_no = [0]
 
+    def step_sort_last():
+        # frame i renders into buffer pair b while the exchange of frame i-1 (the other pair) is still under way
+        b = frame_no[0] & 1
+        frame_no[0] += 1
+        with torch.cuda.stream(stream):
+            stream.wait_event(ev["exchanged"][b])      # the all-to-all that last read this packed frame is done
+            vs.set_packed_output(strips.frames[b].data_ptr(), strips.frames[b].numel() * 8)
+            driver.frame()
+            ev["rendered"][b].record(stream)
+        finish_composites()                            # frame i-1: its minimum and unpack queue behind frame i's kernels
+        with torch.cuda.stream(comm):
+            comm.wait_event(ev["rendered"][b])
+            comm.wait_event(ev["reduced"][b])          # the minimum that last read recv[b] is done
+            strips.exchange(b)
+            ev["exchanged"][b].record(comm)
+        pending.append(b)
+
+    def finish_composites():
+        while pending:
+            b = pending.pop(0)
+            with torch.cuda.stream(stream):
+                stream.wait_event(ev["exchanged"][b])
+                stream.wait_event(ev["collected"][b])  # the gather that last read mine[b] is done
+                strips.reduce(vs, b)
+                ev["reduced"][b].record(stream)
+            with torch.cuda.stream(comm):
+                comm.wait_event(ev["reduced"][b])
+                comm.wait_event(ev["unpacked"][b])
+                done = strips.collect(b)
+                ev["collected"][b].record(comm)
+            if rank == 0:
+                with torch.cuda.stream(stream):
+                    stream.wait_event(ev["collected"][b])
+                    vs.unpack(done.data_ptr())
+                    ev["unpacked"][b].record(stream)
+
     def step():
         if world == 1:
             with torch.cuda.stream(stream):
                 driver.frame()
             return
+        if sort_last:
+            return step_sort_last()
         b = frame_no[0] & 1
         frame_no[0] += 1
         g = gathers[b]
@@ -206,7 +258,10 @@ def main():
                 detiled[b].record(stream)
 
     def fence():
-        detile_pending()
+        if sort_last:
+            finish_composites()
+        else:
+            detile_pending()
         vs.finish()
         torch.cuda.synchronize()
         if world > 1:
@@ -236,7 +291,6 @@ def main():
     fence()
     mean, worst, n_frames = vs.timing_stats()
     stats = vs.frame_stats()
-    n_tris = scene.n_triangles
     ms_per_step = elapsed / args.steps * 1e3
     fps = args.steps / elapsed
     result = None
@@ -282,7 +336,9 @@ def main():
             "config": {"workload": desc if args.scale == 1.0 else f"{desc} (mesh scale {args.scale})",
                        "triangles": n_tris, "width": scene.width, "height": scene.height,
                        "lights": len(scene.lights), "draw_items": stats["n_draw_items"],
-                       "partition": "single GPU" if world == 1 else f"sort-first screen tiles over {world} GPUs, RCCL gather to rank 0"},
+                       "partition": "single GPU" if world == 1 else
+                       (f"sort-last instance shards over {world} GPUs, direct-send depth composite over RCCL" if sort_last else
+                        f"sort-first screen tiles over {world} GPUs, RCCL gather to rank 0")},
             "roofline": roofline_of(dominant),
             # north_star asks for raster AND shade: at this triangle density the raster is the direct
             # small-triangle path inside k_setup (k_raster has no bin entries), so that kernel is reported too

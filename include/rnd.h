@@ -297,6 +297,32 @@ int rnd_packed_device_ptr(rnd_ctx* ctx, void** dev_ptr, uint64_t* n_bytes);
 /* Unpack a (reduced) packed frame on this context's device into its RGBA8 frame (the depth stays in the
  * packed words' upper halves). */
 int rnd_unpack(rnd_ctx* ctx, const void* dev_packed);
+/* Make the packed frame go to caller-owned device memory (16-byte aligned, width*height*8 bytes) instead of the
+ * library's buffer, as rnd_set_tiles_output does for tiles: read when the next frame is enqueued, so two buffers may
+ * alternate while an exchange still reads the other.  Turns the packed output on.  NULL restores the internal buffer. */
+int rnd_set_packed_output(rnd_ctx* ctx, void* dev_ptr, uint64_t n_bytes);
+/* The local step of the sort-last composite: element-wise minimum of n packed strips of `count` words each, strip r at
+ * dev_strips + r*stride_words words (the layout an all-to-all leaves on the rank that owns the strip; stride even and
+ * >= count, pointers 16-byte aligned), into dev_out.  Stream-ordered on the context's stream. */
+int rnd_min_packed(rnd_ctx* ctx, const void* dev_strips, uint32_t n, uint64_t stride_words, void* dev_out, uint64_t count);
+
+/* ---- the exchanges themselves, from C over RCCL (for hosts without Python: the Rust engine) ---------------------
+ * RCCL is loaded by rnd_comm_init (dlopen of librccl.so.1); the library has no link-time dependency on it.  xGMI is
+ * point to point, so both exchanges are groups of ncclSend / ncclRecv in which every peer uses its own link. */
+#define RND_COMM_ID_BYTES 128
+/* rank 0: a fresh communicator id (ncclGetUniqueId), to be handed to the other ranks by whatever channel the host has */
+int rnd_comm_make_id(uint8_t id[RND_COMM_ID_BYTES]);
+/* every rank (one process per GPU): join the communicator of `world` ranks on this context's device */
+int rnd_comm_init(rnd_ctx* ctx, const uint8_t id[RND_COMM_ID_BYTES], uint32_t rank, uint32_t world);
+int rnd_comm_destroy(rnd_ctx* ctx);
+/* Sort-first, collective (every rank calls it after rnd_render; the tile partition must be the communicator's rank and
+ * world): every rank sends its tile-major buffer straight to rank 0, which scatters all of them into its row-major
+ * frame (rnd_color_device_ptr / rnd_read_color_rgba8 there).  Stream-ordered on the context's stream. */
+int rnd_gather_tiles(rnd_ctx* ctx);
+/* Sort-last, collective (every rank calls it after rnd_render of its shard with the packed output on): direct-send
+ * composite — the packed frame is cut into `world` strips, strip s of every rank goes to rank s, rank s takes the
+ * minimum (rnd_min_packed), the finished strips go to rank 0, which unpacks them into its frame. */
+int rnd_composite_packed(rnd_ctx* ctx);
 /* Use the caller's HIP stream (hipStream_t as void*) for this context; NULL = own stream.  Shading, present,
  * the 2D overlay, read-backs, detile/unpack and everything the caller enqueues behind rnd_render are ordered
  * on this stream.  The geometry phase of a frame runs on an internal stream that this one waits for through

@@ -129,6 +129,13 @@ extern "C" {
     pub fn rnd_unset_fullscreen_texture(ctx: *mut rnd_ctx) -> c_int;
     pub fn rnd_read_overlay_rgba8(ctx: *mut rnd_ctx, dst: *mut u8) -> c_int;
     pub fn rnd_tile_info(ctx: *const rnd_ctx, tile_px: *mut u32, n_owned_tiles: *mut u32, n_tiles_total: *mut u32) -> c_int;
+    pub fn rnd_set_packed_output(ctx: *mut rnd_ctx, dev_ptr: *mut c_void, n_bytes: u64) -> c_int;
+    pub fn rnd_min_packed(ctx: *mut rnd_ctx, dev_strips: *const c_void, n: u32, stride_words: u64, dev_out: *mut c_void, count: u64) -> c_int;
+    pub fn rnd_comm_make_id(id: *mut u8) -> c_int;
+    pub fn rnd_comm_init(ctx: *mut rnd_ctx, id: *const u8, rank: u32, world: u32) -> c_int;
+    pub fn rnd_comm_destroy(ctx: *mut rnd_ctx) -> c_int;
+    pub fn rnd_gather_tiles(ctx: *mut rnd_ctx) -> c_int;
+    pub fn rnd_composite_packed(ctx: *mut rnd_ctx) -> c_int;
     pub fn rnd_tiles_device_ptr(ctx: *mut rnd_ctx, dev_ptr: *mut *mut c_void, n_bytes: *mut u64) -> c_int;
     pub fn rnd_set_tiles_output(ctx: *mut rnd_ctx, dev_ptr: *mut c_void, n_bytes: u64) -> c_int;
     pub fn rnd_detile_gathered(ctx: *mut rnd_ctx, world: u32, dev_gathered: *const c_void, stride_bytes: u64) -> c_int;

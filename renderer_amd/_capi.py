@@ -124,12 +124,19 @@ SIGNATURES = {
     "detile_gathered": (C.c_int, [_P, C.c_uint32, _P, C.c_uint64]),
     "packed_device_ptr": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     "unpack": (C.c_int, [_P, _P]),
+    "set_packed_output": (C.c_int, [_P, _P, C.c_uint64]),
+    "min_packed": (C.c_int, [_P, _P, C.c_uint32, C.c_uint64, _P, C.c_uint64]),
+    "comm_make_id": (C.c_int, [_P]),
+    "comm_init": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32]),
+    "comm_destroy": (C.c_int, [_P]),
+    "gather_tiles": (C.c_int, [_P]),
+    "composite_packed": (C.c_int, [_P]),
     "set_stream": (C.c_int, [_P, _P]),
     "color_device_ptr": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
 }
 
 # entry points that only make sense with device memory; a host-only library may omit them
-DEVICE_ONLY = {"mean_timings", "render_noalloc", "time_frames", "timing_stats", "set_tiles_output", "tiles_device_ptr", "detile", "detile_gathered", "packed_device_ptr", "unpack", "set_stream",
+DEVICE_ONLY = {"mean_timings", "render_noalloc", "time_frames", "timing_stats", "set_packed_output", "min_packed", "comm_make_id", "comm_init", "comm_destroy", "gather_tiles", "composite_packed", "set_tiles_output", "tiles_device_ptr", "detile", "detile_gathered", "packed_device_ptr", "unpack", "set_stream",
                "color_device_ptr"}
 
 

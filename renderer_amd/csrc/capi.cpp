@@ -229,6 +229,29 @@ int rnd_packed_device_ptr(rnd_ctx* ctx, void** p, uint64_t* n) {
     return guard(ctx, [&](rnd::VisualServer& v) { v.packed_device_ptr(p, n); });
 }
 int rnd_unpack(rnd_ctx* ctx, const void* dev_packed) { return guard(ctx, [&](rnd::VisualServer& v) { v.unpack(dev_packed); }); }
+int rnd_set_packed_output(rnd_ctx* ctx, void* p, uint64_t n) { return guard(ctx, [&](rnd::VisualServer& v) { v.set_packed_output(p, n); }); }
+int rnd_min_packed(rnd_ctx* ctx, const void* strips, uint32_t n, uint64_t stride_words, void* out, uint64_t count) {
+    return guard(ctx, [&](rnd::VisualServer& v) { v.min_packed(strips, n, stride_words, out, count); });
+}
+int rnd_comm_make_id(uint8_t id[RND_COMM_ID_BYTES]) {
+    if (!id) { g_create_error = "rnd_comm_make_id: null id"; return RND_ERR_INVALID; }
+    try {
+        rnd::comm_make_id(id);
+        return RND_OK;
+    } catch (const rnd::Error& e) {
+        g_create_error = e.what();
+        return e.status;
+    } catch (const std::exception& e) {
+        g_create_error = e.what();
+        return RND_ERR_DEVICE;
+    }
+}
+int rnd_comm_init(rnd_ctx* ctx, const uint8_t id[RND_COMM_ID_BYTES], uint32_t rank, uint32_t world) {
+    return guard(ctx, [&](rnd::VisualServer& v) { v.comm_init(id, rank, world); });
+}
+int rnd_comm_destroy(rnd_ctx* ctx) { return guard(ctx, [&](rnd::VisualServer& v) { v.comm_destroy(); }); }
+int rnd_gather_tiles(rnd_ctx* ctx) { return guard(ctx, [&](rnd::VisualServer& v) { v.gather_tiles(); }); }
+int rnd_composite_packed(rnd_ctx* ctx) { return guard(ctx, [&](rnd::VisualServer& v) { v.composite_packed(); }); }
 int rnd_set_stream(rnd_ctx* ctx, void* s) { return guard(ctx, [&](rnd::VisualServer& v) { v.set_stream(static_cast<hipStream_t>(s)); }); }
 int rnd_color_device_ptr(rnd_ctx* ctx, void** p, uint64_t* n) {
     REQUIRE(ctx, p && n, "null output");

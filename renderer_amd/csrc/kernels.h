@@ -94,6 +94,8 @@ void launch_present(const float* hdr, uint32_t w, uint32_t h, uint8_t* frame_rgb
 // packed (depth | rgba8) row-major -> RGBA8 frame + tile-major vis depth
 // n_tiles = tiles of the surface (32x32); workgroups of tiles another rank owns return at once
 void launch_overlay(const OverlayParams& p, uint32_t n_tiles, hipStream_t stream);
+// element-wise minimum of n packed strips (strip r at strips + r * stride, `count` words each) -> out
+void launch_min_packed(const uint64_t* strips, uint32_t n, uint64_t stride, uint64_t* out, uint64_t count, hipStream_t stream);
 void launch_unpack(const uint64_t* packed, const FrameConst& fc, uint8_t* frame_rgba8, float* depth,
                    hipStream_t stream);
 

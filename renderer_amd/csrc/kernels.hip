@@ -2007,6 +2007,28 @@ __global__ void k_unpack(const unsigned long long* __restrict__ packed, FrameCon
     if (depth) depth[p] = __uint_as_float((uint32_t)(v >> 32));
 }
 
+// Sort-last depth composite of one strip: element-wise minimum of `n` packed (depth bits << 32 | rgba8) strips,
+// strip r at strips + r * stride (the layout an all-to-all leaves on the rank that owns the strip).  Unsigned
+// compare = depth compare (depth in [0, 1]); equal depths resolve by the colour bits.  Two words per lane per load.
+__global__ __launch_bounds__(256) void k_min_packed(const unsigned long long* __restrict__ strips, uint32_t n, uint64_t stride,
+                                                    unsigned long long* __restrict__ out, uint64_t count) {
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    const uint64_t pairs = count / 2u;
+    for (uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x; k < pairs; k += (uint64_t)gridDim.x * 256u) {
+        u64x2 m = reinterpret_cast<const u64x2*>(strips)[k];
+        for (uint32_t r = 1; r < n; ++r) {
+            const u64x2 v = reinterpret_cast<const u64x2*>(strips + r * stride)[k];
+            m.x = v.x < m.x ? v.x : m.x; m.y = v.y < m.y ? v.y : m.y;
+        }
+        reinterpret_cast<u64x2*>(out)[k] = m;
+    }
+    if ((count & 1u) && blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long m = strips[count - 1u];
+        for (uint32_t r = 1; r < n; ++r) { const unsigned long long v = strips[r * stride + count - 1u]; m = v < m ? v : m; }
+        out[count - 1u] = m;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
@@ -2102,6 +2124,12 @@ void launch_present(const float* hdr, uint32_t w, uint32_t h, uint8_t* frame_rgb
 void launch_overlay(const OverlayParams& p, uint32_t n_tiles, hipStream_t stream) {
     if (!n_tiles) return;
     hipLaunchKernelGGL(k_overlay, dim3(n_tiles), dim3(256), 0, stream, p);
+}
+void launch_min_packed(const uint64_t* strips, uint32_t n, uint64_t stride, uint64_t* out, uint64_t count, hipStream_t stream) {
+    if (!count || !n) return;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((count / 2u + 255u) / 256u + 1u, 256u * 16u);
+    hipLaunchKernelGGL(k_min_packed, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const unsigned long long*>(strips), n, stride,
+                       reinterpret_cast<unsigned long long*>(out), count);
 }
 void launch_unpack(const uint64_t* packed, const FrameConst& fc, uint8_t* frame_rgba8, float* depth, hipStream_t stream) {
     size_t n = (size_t)fc.width * fc.height;

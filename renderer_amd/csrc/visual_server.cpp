@@ -127,6 +127,7 @@ VisualServer::VisualServer(uint32_t width, uint32_t height, int device) : device
 
 VisualServer::~VisualServer() {
     (void)hipSetDevice(device_);
+    try { comm_destroy(); } catch (...) {}
     if (geo_stream_) (void)hipStreamSynchronize(geo_stream_);
     if (stream_) (void)hipStreamSynchronize(stream_);
     for (CachedGraph& g : graphs_)
@@ -173,7 +174,7 @@ void VisualServer::apply_size(uint32_t sw, uint32_t sh, float f) {
     if (f != 1.0f && world_ > 1) throw Error(RND_ERR_UNSUPPORTED, "render_size_factor != 1 on a tile partition is not built");
     finish();
     surface_w_ = sw; surface_h_ = sh; width_ = w; height_ = h; render_size_factor_ = f;
-    ext_tiles_ = nullptr; ext_tiles_bytes_ = 0;
+    ext_tiles_ = nullptr; ext_tiles_bytes_ = 0; ext_packed_ = nullptr;
     have_frame_ = false;
     rebuild_tiles();
     if (scaled()) { use_device(); d_present_.ensure((size_t)surface_w_ * surface_h_ * 4); }
@@ -932,7 +933,8 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     last_noalloc_ = noalloc; last_counters_ = bp.counters; last_vis_ = bp.vis; pending_want_hdr_ = want_hdr;
     last_frame_out_ = noalloc && world_ <= 1 ? noalloc_out : d_frame_.ptr;
     last_tiles_out_ = fb.tiles_rgba8;
-    fb.packed = want_packed_ ? d_packed_.ptr : nullptr;
+    fb.packed = want_packed_ ? (ext_packed_ && !noalloc ? ext_packed_ : d_packed_.ptr) : nullptr;
+    last_packed_out_ = fb.packed;
     fb.hdr = want_hdr ? d_hdr_.ptr : nullptr;
 
     // per-kernel timing events on a sample of the frames (every kTimingStride-th, and the first few):
@@ -1373,7 +1375,7 @@ void VisualServer::packed_device_ptr(void** p, uint64_t* bytes) {
         enqueue_frame(false);
         finish();
     }
-    *p = d_packed_.ptr; *bytes = (uint64_t)width_ * height_ * 8;
+    *p = const_cast<uint64_t*>(last_packed_out_ ? last_packed_out_ : d_packed_.ptr); *bytes = (uint64_t)width_ * height_ * 8;
 }
 
 void VisualServer::unpack(const void* dev_packed) {
@@ -1382,10 +1384,27 @@ void VisualServer::unpack(const void* dev_packed) {
     FrameConst fc = fc_;
     fc.width = width_; fc.height = height_;
     launch_unpack(static_cast<const uint64_t*>(dev_packed), fc, d_frame_.ptr, nullptr, stream_);
-    HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipStreamSynchronize(stream_));
+    HIP_CHECK(hipGetLastError());      // (stream-ordered: read-backs and rnd_finish wait on the same stream)
     have_frame_ = true;
     last_frame_out_ = d_frame_.ptr;
+}
+
+void VisualServer::set_packed_output(void* dev_ptr, uint64_t bytes) {
+    // as rnd_set_tiles_output: read when the next frame is enqueued, so a caller may alternate two buffers
+    if (dev_ptr && (bytes < (uint64_t)width_ * height_ * 8 || (reinterpret_cast<uintptr_t>(dev_ptr) & 15u)))
+        throw Error(RND_ERR_INVALID, "packed output buffer too small or not 16-byte aligned");
+    if (scaled()) throw Error(RND_ERR_UNSUPPORTED, "the packed (sort-last) frame is not built for render_size_factor != 1");
+    ext_packed_ = static_cast<uint64_t*>(dev_ptr);
+    if (dev_ptr) want_packed_ = true;
+}
+
+void VisualServer::min_packed(const void* dev_strips, uint32_t n, uint64_t stride_words, void* dev_out, uint64_t count) {
+    if (!dev_strips || !dev_out || n == 0 || (stride_words & 1u) || stride_words < count ||
+        ((reinterpret_cast<uintptr_t>(dev_strips) | reinterpret_cast<uintptr_t>(dev_out)) & 15u))
+        throw Error(RND_ERR_INVALID, "bad strips: null, odd stride, stride below count, or not 16-byte aligned");
+    use_device();
+    launch_min_packed(static_cast<const uint64_t*>(dev_strips), n, stride_words, static_cast<uint64_t*>(dev_out), count, stream_);
+    HIP_CHECK(hipGetLastError());
 }
 
 void VisualServer::set_stream(hipStream_t s) {
@@ -1405,5 +1424,6 @@ void VisualServer::color_device_ptr(void** p, uint64_t* bytes) {
 template struct DeviceBuffer<float>;
 template struct DeviceBuffer<uint32_t>;
 template struct DeviceBuffer<uint8_t>;
+template struct DeviceBuffer<uint64_t>;
 
 }  // namespace rnd

@@ -24,6 +24,8 @@ struct Error : std::runtime_error {
 };
 
 void check_hip(hipError_t e, const char* what);
+#define HIP_CHECK_COMM(x) ::rnd::check_hip((x), #x)
+void comm_make_id(uint8_t* id);      // ncclGetUniqueId (comm.cpp)
 
 using UniqueNodeId = uint64_t;   // src/scene.rs:14-15 flattened to 64 bits
 
@@ -145,6 +147,13 @@ public:
     void unpack(const void* dev_packed);
     void set_stream(hipStream_t s);
     void color_device_ptr(void** p, uint64_t* bytes);
+    void set_packed_output(void* dev_ptr, uint64_t bytes);
+    void min_packed(const void* dev_strips, uint32_t n, uint64_t stride_words, void* dev_out, uint64_t count);
+    // RCCL exchanges from C (comm.cpp)
+    void comm_init(const uint8_t* id, uint32_t rank, uint32_t world);
+    void comm_destroy();
+    void gather_tiles();
+    void composite_packed();
 
     // for tests of the host logic
     const Mat4& projection() const { return projection_; }
@@ -201,6 +210,11 @@ private:
     void harvest(EventSet& s);
     uint8_t* ext_tiles_ = nullptr;
     uint64_t ext_tiles_bytes_ = 0;
+    uint64_t* ext_packed_ = nullptr;          // rnd_set_packed_output
+    const uint64_t* last_packed_out_ = nullptr;
+    void* comm_ = nullptr;                    // ncclComm_t
+    uint32_t comm_rank_ = 0, comm_world_ = 0;
+    DeviceBuffer<uint64_t> d_comm_a_, d_comm_b_;      // exchange buffers of gather_tiles / composite_packed
 
     // RenderScene — visual_server.rs:896-905 (insertion-ordered instead of HashMap order)
     std::unordered_map<uint32_t, RenderMesh> meshes_;

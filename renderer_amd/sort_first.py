@@ -83,3 +83,54 @@ def unpack_numpy(packed):
     depth = (p >> np.uint64(32)).astype(np.uint32).view(np.float32)
     rgba = (p & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.uint8).reshape(p.shape + (4,))
     return depth, rgba
+
+
+CLEAR_KEY = (0x3F800000 << 32) | 0xFFFFFFFF        # depth 1.0 in the high half: loses every comparison
+
+
+class StripComposite:
+    """Sort-last direct-send composite: the packed frame is cut into `world` equal strips, strip s
+    of every rank goes to rank s (all-to-all: every pair over its own xGMI link, no ring), rank s takes the
+    element-wise minimum (rnd_min_packed), the finished strips are gathered on rank 0.  Two sets of buffers, so the
+    exchange of one frame can run beside the rendering of the next."""
+
+    def __init__(self, rank, world, n_pixels, device):
+        self.rank, self.world, self.n_pixels = rank, world, n_pixels
+        self.strip = ((n_pixels + world - 1) // world + 1) & ~1          # words per strip, even (16-byte loads)
+        n = world * self.strip
+        # render targets of the packed frame (rnd_set_packed_output), padded to whole strips with the clear key
+        self.frames = [torch.full((n,), CLEAR_KEY, dtype=torch.int64, device=device) for _ in range(2)]
+        self.recv = [torch.empty((world, self.strip), dtype=torch.int64, device=device) for _ in range(2)]
+        self.mine = [torch.empty(self.strip, dtype=torch.int64, device=device) for _ in range(2)]
+        self.done = [torch.empty((world, self.strip), dtype=torch.int64, device=device) if rank == 0 else None for _ in range(2)]
+
+    def exchange(self, b):
+        """All-to-all of buffer pair b's strips (collective)."""
+        frame, recv = self.frames[b], self.recv[b]
+        if dist.get_backend() == "gloo":
+            # rehearsal on a box with fewer GPUs than ranks: gloo has no all-to-all; every rank gets every frame on the
+            # host and keeps its strip of each
+            host = frame.cpu()
+            parts = [torch.empty_like(host) for _ in range(self.world)]
+            dist.all_gather(parts, host)
+            s = self.strip
+            recv.copy_(torch.stack([p[self.rank * s:(self.rank + 1) * s] for p in parts]))
+            return
+        dist.all_to_all_single(recv.view(-1), frame)
+
+    def reduce(self, vs, b):
+        """Minimum of the received strips on the context's stream."""
+        vs.min_packed(self.recv[b].data_ptr(), self.world, self.strip, self.mine[b].data_ptr(), self.strip)
+
+    def collect(self, b):
+        """Finished strips to rank 0 (collective); returns the whole packed frame there."""
+        mine, done = self.mine[b], self.done[b]
+        if dist.get_backend() == "gloo":
+            host = mine.cpu()
+            parts = [torch.empty_like(host) for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(host, parts, dst=0)
+            if self.rank == 0:
+                done.copy_(torch.stack(parts))
+            return done
+        dist.gather(mine, [done[r] for r in range(self.world)] if self.rank == 0 else None, dst=0)
+        return done

@@ -373,5 +373,32 @@ class VisualServer:
     def unpack(self, dev_ptr):
         self._check(self.api.unpack(self._ctx, C.c_void_p(dev_ptr)))
 
+    def set_packed_output(self, dev_ptr, n_bytes):
+        self._check(self.api.set_packed_output(self._ctx, C.c_void_p(dev_ptr), int(n_bytes)))
+
+    def min_packed(self, strips_ptr, n, stride_words, out_ptr, count):
+        """rnd_min_packed: the local step of the sort-last composite, on this context's stream."""
+        self._check(self.api.min_packed(self._ctx, C.c_void_p(strips_ptr), int(n), int(stride_words), C.c_void_p(out_ptr), int(count)))
+
+    def comm_make_id(self):
+        buf = np.zeros(128, np.uint8)
+        rc = self.api.comm_make_id(buf.ctypes.data)
+        if rc != 0:
+            raise RndError(rc, (self.api.last_error(None) or b"").decode())
+        return buf
+
+    def comm_init(self, comm_id, rank, world):
+        buf = np.ascontiguousarray(comm_id, dtype=np.uint8)
+        self._check(self.api.comm_init(self._ctx, buf.ctypes.data, int(rank), int(world)))
+
+    def comm_destroy(self):
+        self._check(self.api.comm_destroy(self._ctx))
+
+    def gather_tiles(self):
+        self._check(self.api.gather_tiles(self._ctx))
+
+    def composite_packed(self):
+        self._check(self.api.composite_packed(self._ctx))
+
     def set_stream(self, hip_stream):
         self._check(self.api.set_stream(self._ctx, C.c_void_p(hip_stream)))
