@@ -169,7 +169,8 @@ _PRODUCT = None
 
 
 def product_library_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "librnd_amd.so")
+    # RND_LIBRARY: another build of the same library (A/B timing of two builds in one GPU call); no other backend exists
+    return os.environ.get("RND_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "librnd_amd.so")
 
 
 def load_product():

@@ -123,7 +123,16 @@ struct FrameConst {
                                    // geometry pass resolves, moved onto the pixel centre (0 without MSAA)
     double ndc_step_x, ndc_step_y;   // 2/width, 2/height in f64 (pixel centre -> NDC at shade time)
     float ndc_step_xf, ndc_step_yf;  // the same in f32
+    // Multi-view passes (the four shadow cascades of a directional light in ONE geometry pass): the views are
+    // stacked vertically in one tall render target of width x (n_views * view_h); view v has its own
+    // projection * view (pv for view 0, pv_more[v - 1] above), its viewport is rows [v * view_h, (v + 1) * view_h)
+    // and doubles as its scissor.  A work unit is (draw item, chunk, view); n_units counts all of them,
+    // n_units_view those of one view.  Single-view passes: n_views 1, view_h = height, n_units_view = n_units.
+    uint32_t n_views, view_h, view_mask, n_units_view;
+    float pv_more[3][16];
 };
+constexpr uint32_t kMaxViews = 4;
+constexpr uint32_t kUnitViewShift = 28;        // active_units.y = chunk | view << 28
 
 // Setup record of one (sub-)triangle after cull / clip / snap: 48 bytes.
 struct SetupRecord {

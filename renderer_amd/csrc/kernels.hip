@@ -118,7 +118,10 @@ __device__ __forceinline__ DrawItem load_item_uniform(const DrawItem* items, uin
 
 // vs_main's clip position (render_mesh.wgsl:42-82).  K1 stores it; the shading kernel re-derives
 // it from the object-space position it gathers anyway: same inputs, same operations, same bits.
-__device__ __forceinline__ float4 clip_position(const DrawItem& d, FrameConstRef fc, float x, float y, float z) {
+// projection * view of view `v` of the pass (FrameConst: multi-view passes)
+__device__ __forceinline__ cptr_f32 view_pv(FrameConstRef fc, uint32_t v) { return v == 0u ? fc.pv : fc.pv_more[v - 1u]; }
+
+__device__ __forceinline__ float4 clip_position(const DrawItem& d, cptr_f32 p, float x, float y, float z) {
     float4 c;
     if ((d.flags & kItemBillboardMask) == RND_BILLBOARD_FIXED_SIZE) {
         c = make_float4(d.fixed_clip[0] + x * 0.4f, d.fixed_clip[1] + y * 0.4f, d.fixed_clip[2], d.fixed_clip[3]);
@@ -128,7 +131,6 @@ __device__ __forceinline__ float4 clip_position(const DrawItem& d, FrameConstRef
         float wy = ((m[1] * x + m[5] * y) + m[9] * z) + m[13];
         float wz = ((m[2] * x + m[6] * y) + m[10] * z) + m[14];
         float ww = ((m[3] * x + m[7] * y) + m[11] * z) + m[15];
-        cptr_f32 p = fc.pv;
         c.x = ((p[0] * wx + p[4] * wy) + p[8] * wz) + p[12] * ww;
         c.y = ((p[1] * wx + p[5] * wy) + p[9] * wz) + p[13] * ww;
         c.z = ((p[2] * wx + p[6] * wy) + p[10] * wz) + p[14] * ww;
@@ -172,11 +174,15 @@ __global__ __launch_bounds__(256) void k_clear(FrameBuffers fb, uint32_t n_count
 // blocks they read.
 __global__ __launch_bounds__(256) void k_cull(FrameBuffers fb) {
     FrameConstRef fc = frame_const_ref(fb.frame_const);
-    const uint32_t u = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t gu = blockIdx.x * 256u + threadIdx.x;
     const uint32_t lane = lane_id();
     bool active = false;
     uint32_t it = 0, chunk = 0, vb0 = 0, vb1 = 0;
-    if (u < fc.n_units) {
+    // (unit, view): the views of a multi-view pass are culled one by one against their own volume
+    const uint32_t per_view = max(fc.n_units_view, 1u);
+    const uint32_t view = gu / per_view, u = gu - view * per_view;
+    const uint32_t n_vblocks = (fc.n_verts + kVertexBlock - 1) / kVertexBlock;
+    if (gu < fc.n_units && ((fc.view_mask >> view) & 1u)) {
         it = find_item(fb.unit_bases, fc.n_items, u);
         const DrawItem& d = fb.items[it];
         chunk = u - d.unit_base;
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(256) void k_cull(FrameBuffers fb) {
                 bool out_l = true, out_r = true, out_b = true, out_t = true, out_n = true, out_f = true, w_pos = true;
                 float y_lo = 3.0e38f, y_hi = -3.0e38f;
                 for (uint32_t c = 0; c < 8; ++c) {
-                    const float4 p = clip_position(d, fc, (c & 1u) ? ci.hi[0] : ci.lo[0], (c & 2u) ? ci.hi[1] : ci.lo[1],
+                    const float4 p = clip_position(d, view_pv(fc, view), (c & 1u) ? ci.hi[0] : ci.lo[0], (c & 2u) ? ci.hi[1] : ci.lo[1],
                                                    (c & 4u) ? ci.hi[2] : ci.lo[2]);
                     const float e = 1.0e-3f * (fabsf(p.x) + fabsf(p.y) + fabsf(p.z) + fabsf(p.w)) + 1.0e-30f;
                     out_l = out_l && (p.x + p.w < -e); out_r = out_r && (p.w - p.x < -e);
@@ -227,10 +233,9 @@ __global__ __launch_bounds__(256) void k_cull(FrameBuffers fb) {
         if (lane == (uint32_t)leader) base = atomicAdd(&fb.counters->n_active, (uint32_t)__popcll(am));
         base = __shfl(base, leader);
         if (active) {
-            fb.active_units[base + (uint32_t)__popcll(am & ((1ull << lane) - 1ull))] = make_uint2(it, chunk);
-            const uint32_t n_vblocks = (fc.n_verts + kVertexBlock - 1) / kVertexBlock;
+            fb.active_units[base + (uint32_t)__popcll(am & ((1ull << lane) - 1ull))] = make_uint2(it, chunk | (view << kUnitViewShift));
             if (vb1 - vb0 >= 64u) fb.counters->all_verts = 1u;
-            else for (uint32_t b = vb0; b <= vb1 && b < n_vblocks; ++b) fb.vblock_needed[b] = 1u;
+            else for (uint32_t b = vb0; b <= vb1 && b < n_vblocks; ++b) fb.vblock_needed[view * n_vblocks + b] = 1u;
         }
     }
 }
@@ -262,9 +267,13 @@ __global__ __launch_bounds__(256) void k_transform(const DrawItem* __restrict__ 
                                                    const FrameCounters* __restrict__ counters) {
     FrameConstRef fc = frame_const_ref(fcp);
     static_assert(kVertexBlock == 256, "one workgroup per vertex block");
-    if (!vblock_needed[blockIdx.x] && !counters->all_verts) return;      // no surviving work unit reads this block
+    const uint32_t view = blockIdx.y;                                    // multi-view passes: one grid row per view
+    if (!((fc.view_mask >> view) & 1u)) return;
+    if (!vblock_needed[view * gridDim.x + blockIdx.x] && !counters->all_verts) return;      // no surviving work unit reads this block
     uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     if (gid >= fc.n_verts) return;
+    const size_t out_base = (size_t)view * fc.n_verts;
+    const int32_t view_dy = (int32_t)(view * fc.view_h) * kSub;          // the view's rows in the stacked target
     uint32_t it = find_item(vert_bases, fc.n_items, gid);
     for (unsigned long long pending = __ballot(true); pending;) {
         uint32_t cur_s, cur = uniform_pick(it, pending, cur_s);
@@ -274,10 +283,10 @@ __global__ __launch_bounds__(256) void k_transform(const DrawItem* __restrict__ 
             const DrawItem d = load_item_uniform(items, cur_s);
             uint32_t v = gid - d.vert_base;
             float x = ((gptr_f32)d.px)[v], y = ((gptr_f32)d.py)[v], z = ((gptr_f32)d.pz)[v];
-            float4 c = clip_position(d, fc, x, y, z);
-            clip[gid] = c;
-            const SnapVert sv = snap_and_classify(c, 0.5f * (float)fc.width, 0.5f * (float)fc.height);
-            *reinterpret_cast<uint4*>(snap + gid) = make_uint4((uint32_t)sv.x, (uint32_t)sv.y, __float_as_uint(sv.z), sv.code);
+            float4 c = clip_position(d, view_pv(fc, view), x, y, z);
+            clip[out_base + gid] = c;
+            const SnapVert sv = snap_and_classify(c, 0.5f * (float)fc.width, 0.5f * (float)fc.view_h);
+            *reinterpret_cast<uint4*>(snap + out_base + gid) = make_uint4((uint32_t)sv.x, (uint32_t)(sv.y + view_dy), __float_as_uint(sv.z), sv.code);
         }
     }
 }
@@ -308,8 +317,9 @@ struct TileRect {
 };
 
 // Cull + bbox + record of one snapped triangle.  Returns false when nothing can be covered.
+// j_lo .. j_hi: the pixel rows of the triangle's view (its viewport and scissor; the whole frame in single-view passes)
 __device__ __forceinline__ bool make_record(const Snapped& a, const Snapped& b, const Snapped& c,
-                                            uint32_t tri_id, FrameConstRef fc, SetupRecord& r,
+                                            uint32_t tri_id, FrameConstRef fc, int32_t j_lo, int32_t j_hi, SetupRecord& r,
                                             TileRect& tr) {
     long long A2 = (long long)(b.x - a.x) * (c.y - a.y) - (long long)(c.x - a.x) * (b.y - a.y);
     long long area2 = -A2;
@@ -320,8 +330,8 @@ __device__ __forceinline__ bool make_record(const Snapped& a, const Snapped& b, 
     // pixel centres i*256+128 inside the closed bbox
     int32_t i0 = max((xmin - kSub / 2 + kSub - 1) >> kSubpixelBits, 0);
     int32_t i1 = min((xmax - kSub / 2) >> kSubpixelBits, (int32_t)fc.width - 1);
-    int32_t j0 = max((ymin - kSub / 2 + kSub - 1) >> kSubpixelBits, 0);
-    int32_t j1 = min((ymax - kSub / 2) >> kSubpixelBits, (int32_t)fc.height - 1);
+    int32_t j0 = max((ymin - kSub / 2 + kSub - 1) >> kSubpixelBits, j_lo);
+    int32_t j1 = min((ymax - kSub / 2) >> kSubpixelBits, j_hi);
     r.x0 = a.x; r.y0 = a.y; r.x1 = b.x; r.y1 = b.y; r.x2 = c.x; r.y2 = c.y;
     r.z0 = a.z; r.dz1 = b.z - a.z; r.dz2 = c.z - a.z;
     r.inv_area = 1.0f / (float)area2;
@@ -585,7 +595,8 @@ __device__ __forceinline__ uint32_t count_wave(bool emit, const TileRect& t, uin
 // Reject / cull / record of one triangle from its three pre-snapped vertices (K1 did the per-vertex
 // work: snap_and_classify); sets need_clip (and emits nothing) when it must go through the clipper.
 __device__ __forceinline__ void setup_triangle(const SnapVert& v0, const SnapVert& v1, const SnapVert& v2, uint32_t gid,
-                                               FrameConstRef fc, SetupRecord& rec, TileRect& tr, bool& emit, bool& need_clip) {
+                                               FrameConstRef fc, int32_t j_lo, int32_t j_hi, SetupRecord& rec, TileRect& tr, bool& emit,
+                                               bool& need_clip) {
     const uint32_t any = v0.code | v1.code | v2.code, all = v0.code & v1.code & v2.code;
     // dropped: a non-finite coordinate, or all three vertices outside one plane of the view volume
     const bool go = !(any & kOutNonFinite) && !(all & kOutPlanes);
@@ -593,7 +604,7 @@ __device__ __forceinline__ void setup_triangle(const SnapVert& v0, const SnapVer
     if (go && !need_clip) {
         const Snapped s0{v0.x + fc.sub_dx, v0.y + fc.sub_dy, v0.z}, s1{v1.x + fc.sub_dx, v1.y + fc.sub_dy, v1.z},
                       s2{v2.x + fc.sub_dx, v2.y + fc.sub_dy, v2.z};
-        const bool rec_ok = make_record(s0, s1, s2, gid, fc, rec, tr);
+        const bool rec_ok = make_record(s0, s1, s2, gid, fc, j_lo, j_hi, rec, tr);
         emit = !(any & kOutBehind) && rec_ok && any_owned(tr, fc);
     }
 }
@@ -684,7 +695,10 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
     if (blockIdx.x >= fb.counters->n_active) return;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     const uint2 unit = fb.active_units[blockIdx.x];
-    const uint32_t item_s = __builtin_amdgcn_readfirstlane(unit.x), chunk_s = __builtin_amdgcn_readfirstlane(unit.y);
+    const uint32_t item_s = __builtin_amdgcn_readfirstlane(unit.x), chunk_s = __builtin_amdgcn_readfirstlane(unit.y) & ((1u << kUnitViewShift) - 1u);
+    const uint32_t view_s = __builtin_amdgcn_readfirstlane(unit.y) >> kUnitViewShift;
+    const int32_t j_lo = (int32_t)(view_s * fc.view_h), j_hi = j_lo + (int32_t)fc.view_h - 1;       // the view's rows
+    const SnapVert* const snap_v = fb.snap + (size_t)view_s * fc.n_verts;
     if (!guard(item_s < fc.n_items, fb.counters, kGuardSetup)) return;      // uniform over the workgroup
     if (threadIdx.x == 0) s_used = 0;
     __syncthreads();
@@ -713,16 +727,16 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
             const uint32_t i0 = ix[0], i1 = ix[1], i2 = ix[2];
             if (guard(i0 < nv && i1 < nv && i2 < nv, fb.counters, kGuardSetup)) {
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                u32x4 q0 = *reinterpret_cast<const u32x4*>(fb.snap + vb + i0);
-                u32x4 q1 = *reinterpret_cast<const u32x4*>(fb.snap + vb + i1);
-                u32x4 q2 = *reinterpret_cast<const u32x4*>(fb.snap + vb + i2);
+                u32x4 q0 = *reinterpret_cast<const u32x4*>(snap_v + vb + i0);
+                u32x4 q1 = *reinterpret_cast<const u32x4*>(snap_v + vb + i1);
+                u32x4 q2 = *reinterpret_cast<const u32x4*>(snap_v + vb + i2);
                 // three whole 16-byte gathers in one round trip: left alone the compiler loads the outcodes
                 // first and sinks the positions into the branch that uses them (six gathers, two round trips)
                 asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2));
                 const SnapVert v0{(int32_t)q0.x, (int32_t)q0.y, __uint_as_float(q0.z), q0.w};
                 const SnapVert v1{(int32_t)q1.x, (int32_t)q1.y, __uint_as_float(q1.z), q1.w};
                 const SnapVert v2{(int32_t)q2.x, (int32_t)q2.y, __uint_as_float(q2.z), q2.w};
-                setup_triangle(v0, v1, v2, gid, fc, rec, tr, emit, need_clip);
+                setup_triangle(v0, v1, v2, gid, fc, j_lo, j_hi, rec, tr, emit, need_clip);
                 if (alpha_item) rec.flags |= 2u;
             }
         }
@@ -735,7 +749,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
             base = __shfl(base, leader);
             if (need_clip) {
                 uint32_t q = base + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull));
-                if (q < cap.clip_queue) fb.clip_queue[q] = gid; else atomicOr(&fb.counters->overflow, 2u);
+                if (q < cap.clip_queue) { fb.clip_queue[q] = gid; fb.clip_queue[cap.clip_queue + q] = view_s; } else atomicOr(&fb.counters->overflow, 2u);
             }
         }
         valid += (uint32_t)__popcll(__ballot(emit));
@@ -831,9 +845,10 @@ __global__ __launch_bounds__(256) void k_clip(FrameBuffers fb, Capacities cap) {
         const uint32_t q = q0 + threadIdx.x;
         Snapped s[12];
         int fan = 0;                        // triangles of this lane's fan
-        uint32_t gid = 0, alpha = 0;
+        uint32_t gid = 0, alpha = 0, view = 0;
         if (q < n) {
             gid = fb.clip_queue[q];
+            view = min(fb.clip_queue[cap.clip_queue + q], kMaxViews - 1u);
             uint32_t it = find_item(fb.tri_bases, fc.n_items, gid);
             const DrawItem& d = fb.items[it];
             uint32_t t = gid - d.tri_base;
@@ -841,7 +856,7 @@ __global__ __launch_bounds__(256) void k_clip(FrameBuffers fb, Capacities cap) {
             alpha = (d.flags & kItemAlphaTest) ? 2u : 0u;
             ClipVert a[12], b[12];
             for (int k = 0; k < 3; ++k) {
-                float4 c = fb.clip[d.vert_base + ix[k]];
+                float4 c = fb.clip[(size_t)view * fc.n_verts + d.vert_base + ix[k]];
                 a[k] = ClipVert{c.x, c.y, c.z, c.w};
             }
             int cnt = 3;
@@ -859,9 +874,10 @@ __global__ __launch_bounds__(256) void k_clip(FrameBuffers fb, Capacities cap) {
                 for (int k = 0; k < cnt; ++k) a[k] = b[k];
             }
             if (cnt >= 3) {
-                float half_w = 0.5f * (float)fc.width, half_h = 0.5f * (float)fc.height;
+                float half_w = 0.5f * (float)fc.width, half_h = 0.5f * (float)fc.view_h;
                 bool ok = true;
-                for (int k = 0; k < cnt; ++k) { bool o = snap_vertex(a[k].x, a[k].y, a[k].z, a[k].w, half_w, half_h, s[k], fc.sub_dx, fc.sub_dy); ok = ok && o; }
+                const int32_t view_dy = (int32_t)(view * fc.view_h) * kSub;
+                for (int k = 0; k < cnt; ++k) { bool o = snap_vertex(a[k].x, a[k].y, a[k].z, a[k].w, half_w, half_h, s[k], fc.sub_dx, fc.sub_dy + view_dy); ok = ok && o; }
                 if (ok) fan = cnt - 2;
             }
         }
@@ -869,7 +885,7 @@ __global__ __launch_bounds__(256) void k_clip(FrameBuffers fb, Capacities cap) {
             bool emit = k <= fan;
             SetupRecord rec;
             TileRect tr{0, 0, 0, 0, 0, 0, 0, 0};
-            if (emit) emit = make_record(s[0], s[k], s[k + 1], gid, fc, rec, tr) && any_owned(tr, fc);
+            if (emit) emit = make_record(s[0], s[k], s[k + 1], gid, fc, (int32_t)(view * fc.view_h), (int32_t)((view + 1u) * fc.view_h) - 1, rec, tr) && any_owned(tr, fc);
             if (emit) {
                 rec.flags |= alpha;
                 const uint32_t slot = cap.setup_slots + atomicAdd(&fb.counters->n_records, 1u);
@@ -2037,7 +2053,7 @@ static inline uint32_t div_up(uint64_t a, uint32_t b) { return (uint32_t)((a + b
 void launch_clear(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream, const void* host_tables,
                   void* dev_tables, size_t table_bytes) {
     const uint32_t n_counts = 2u * fc.tiles_x * fc.tiles_y;
-    const uint32_t n_vblocks = (fc.n_verts + kVertexBlock - 1) / kVertexBlock;
+    const uint32_t n_vblocks = (fc.n_verts + kVertexBlock - 1) / kVertexBlock * std::max(fc.n_views, 1u);
     const uint32_t n_vec = (uint32_t)(table_bytes / 16);
     // enough workgroups for the table copy even when this context owns few tiles
     const uint32_t blocks = std::max<uint32_t>(fb.n_owned ? fb.n_owned : 1u, std::min<uint32_t>(div_up(n_vec, 256), 1024u));
@@ -2051,7 +2067,7 @@ void launch_cull(const FrameBuffers& fb, const FrameConst& fc, hipStream_t strea
 
 void launch_transform(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream) {
     if (!fc.n_verts) return;
-    hipLaunchKernelGGL(k_transform, dim3(div_up(fc.n_verts, 256)), dim3(256), 0, stream, fb.items, fb.vert_bases, fb.frame_const, fb.clip, fb.snap,
+    hipLaunchKernelGGL(k_transform, dim3(div_up(fc.n_verts, 256), std::max(fc.n_views, 1u)), dim3(256), 0, stream, fb.items, fb.vert_bases, fb.frame_const, fb.clip, fb.snap,
                        fb.vblock_needed, fb.counters);
 }
 void launch_setup(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {

@@ -140,7 +140,7 @@ VisualServer::~VisualServer() {
     d_tile_offset_.release(); d_tile_cursor_.release(); d_entries_.release();
     for (auto& kv : textures_) kv.second.texels.release();
     d_textures_.release();
-    d_shadow_order_.release();
+    for (auto& b : d_shadow_order_) b.release();
     for (auto& v : shadow_layers_) for (auto& b : v) b.release();
     d_launch_order_.release(); d_frame_.release(); d_tiles_.release(); d_packed_.release();
     d_hdr_.release(); d_font_.release(); d_srgb_lut_.release(); d_overlay_.release(); d_present_.release();
@@ -616,6 +616,7 @@ void VisualServer::build_frame(std::vector<DrawItem>& items, std::vector<uint32_
     fc.ndc_step_x = 2.0 / (double)width_; fc.ndc_step_y = 2.0 / (double)height_;
     fc.ndc_step_xf = (float)fc.ndc_step_x; fc.ndc_step_yf = (float)fc.ndc_step_y;
     fc.n_samples = msaa_;
+    fc.n_views = 1; fc.view_h = height_; fc.view_mask = 1u; fc.n_units_view = fc.n_units;      // (multi-view: the shadow passes only)
     fc.sub_dx = fc.sub_dy = 0;
     if (msaa_ > 1) sample_shift(0, fc.sub_dx, fc.sub_dy);
 }
@@ -716,8 +717,12 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         if (lights[i].kind == RND_LIGHT_DIRECTIONAL) { lights[i].shadow_index = (int32_t)shadowed.size(); shadowed.push_back(i); }
     const uint32_t n_sets = fc_.n_tris ? (uint32_t)shadowed.size() : 0u;
     if (!n_sets) for (auto& l : lights) l.shadow_index = -1;
-    const uint32_t n_passes = n_sets * kShadowCascades;
+    // every shadowed light is ONE multi-view geometry pass: its four cascades are the views, stacked vertically in a
+    // kShadowSize x 4*kShadowSize target (the four contiguous layers of the light's maps)
+    const uint32_t n_passes = n_sets;
     constexpr uint32_t kShadowTiles = (kShadowSize / kTile) * (kShadowSize / kTile);
+    const uint32_t n_views_max = n_sets ? kShadowCascades : 1u;        // views of the frame's widest pass (buffer sizes)
+    static_assert(kShadowCascades <= kMaxViews && kShadowCascades * kShadowSize <= kMaxRenderSize, "the cascades must stack into one render target");
     const bool overlay = fullscreen_ != 0 || !uiboxes_.empty() || !glyphs_.empty();
     if (noalloc) {
         // what the scratch array cannot hold or what would need a new allocation
@@ -739,13 +744,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
             for (int c = 0; c < 3; ++c) rl.cascades[c].to_cols_array(sets[k].world_to_light[c]);
             for (uint32_t c = 0; c < kShadowCascades; ++c) sets[k].layers[c] = shadow_layers_[p][k].ptr + (size_t)c * kShadowTiles * kTilePixels;
         }
-        if (!d_shadow_order_.ptr) {
-            std::vector<TileRef> order(kShadowTiles);
-            for (uint32_t t = 0; t < kShadowTiles; ++t) order[t] = TileRef{t, t};
-            d_shadow_order_.ensure(kShadowTiles);
-            HIP_CHECK(hipMemcpy(d_shadow_order_.ptr, order.data(), kShadowTiles * sizeof(TileRef), hipMemcpyHostToDevice));
-        }
-        const size_t need = std::max<size_t>((size_t)tiles_x_ * tiles_y_, kShadowTiles);
+        const size_t need = std::max<size_t>((size_t)tiles_x_ * tiles_y_, (size_t)kShadowCascades * kShadowTiles);
         d_tile_count_.ensure(2 * need); d_tile_offset_.ensure(need); d_tile_cursor_.ensure(need);
     }
     // (members that describe "the last enqueued frame" change only after the last point where this one can be rejected)
@@ -762,7 +761,8 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     const size_t n_tiles = (size_t)tiles_x_ * tiles_y_;
 
     // capacities
-    cap_.setup_slots = fc.n_units * fc.chunk_tris;
+    if ((uint64_t)fc.n_units * n_views_max * fc.chunk_tris >= 0xFFFFFFF0ull) throw Error(RND_ERR_INVALID, "frame exceeds 2^32 record slots");
+    cap_.setup_slots = fc.n_units * n_views_max * fc.chunk_tris;
     // (RND_TEST_SMALL_STREAMS: floors so small that ordinary test scenes overflow them, for the tests of that path)
     const uint32_t floor_clip_records = test_small_streams_ ? 8u : fc.n_tris / 8 + 4096;
     const uint32_t floor_clip_queue = test_small_streams_ ? 16u : std::max<uint32_t>(fc.n_tris / 8, 65536);
@@ -779,13 +779,15 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
             *wide_list, *tile_slices, *tile_count, *tile_offset, *tile_cursor;
         uint2* raster_extra; FrameCounters* counters; uint64_t* vis;
     } bp{};
-    const size_t n_vblocks = (size_t)fc.n_verts / kVertexBlock + 2;
+    const size_t n_vblocks = ((size_t)fc.n_verts / kVertexBlock + 2) * n_views_max;
+    const size_t n_unit_words = std::max<size_t>(2 * (size_t)fc.n_units * n_views_max, 2);
+    const size_t n_view_verts = std::max<size_t>((size_t)fc.n_verts * n_views_max, 1);
     if (noalloc) {
-        bp.clip = arena.take<float4>(fc.n_verts); bp.snap = arena.take<SnapVert>(fc.n_verts);
+        bp.clip = arena.take<float4>(n_view_verts); bp.snap = arena.take<SnapVert>(n_view_verts);
         bp.records = arena.take<SetupRecord>(cap_.records); bp.tilewords = arena.take<uint32_t>(2 * (size_t)cap_.records);
-        bp.clip_queue = arena.take<uint32_t>(cap_.clip_queue);
-        bp.chunk_count = arena.take<uint32_t>(std::max<size_t>(2 * (size_t)fc.n_units, 2));
-        bp.active_units = arena.take<uint32_t>(std::max<size_t>(2 * (size_t)fc.n_units, 2));
+        bp.clip_queue = arena.take<uint32_t>(2 * (size_t)cap_.clip_queue);      // triangle ids, then their views
+        bp.chunk_count = arena.take<uint32_t>(n_unit_words);
+        bp.active_units = arena.take<uint32_t>(n_unit_words);
         bp.vblock_needed = arena.take<uint32_t>(n_vblocks);
         bp.entries = arena.take<uint32_t>(cap_.entries);
         bp.wide_list = arena.take<uint32_t>(cap_.wide_list);
@@ -795,16 +797,16 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         bp.counters = arena.take<FrameCounters>(n_counter_sets);
         bp.vis = arena.take<uint64_t>(n_tiles * kTilePixels * msaa_);
     } else {
-        d_clip_[p].ensure(std::max<size_t>(fc.n_verts, 1));
-        d_snap_.ensure(std::max<size_t>(fc.n_verts, 1));
+        d_clip_[p].ensure(n_view_verts);
+        d_snap_.ensure(n_view_verts);
         d_records_.ensure(cap_.records); d_tilewords_.ensure(2 * (size_t)cap_.records);
-        d_clip_queue_.ensure(cap_.clip_queue);
-        d_chunk_count_.ensure(std::max<size_t>(2 * (size_t)fc.n_units, 2));
-        d_active_units_.ensure(std::max<size_t>(2 * (size_t)fc.n_units, 2));
+        d_clip_queue_.ensure(2 * (size_t)cap_.clip_queue);
+        d_chunk_count_.ensure(n_unit_words);
+        d_active_units_.ensure(n_unit_words);
         d_vblock_needed_.ensure(n_vblocks);
         d_entries_.ensure(cap_.entries);
         d_wide_list_.ensure(cap_.wide_list);
-        d_tile_slices_.ensure(std::max<size_t>(n_tiles, n_sets ? kShadowTiles : 0));
+        d_tile_slices_.ensure(std::max<size_t>(n_tiles, n_sets ? (size_t)kShadowCascades * kShadowTiles : 0));
         d_raster_extra_.ensure(kRasterExtraCap);
         if (world_ > 1) d_tiles_.ensure(std::max<size_t>((size_t)n_owned_ * kTilePixels * 4, 4));
         if (want_packed_) d_packed_.ensure((size_t)width_ * height_);
@@ -828,14 +830,26 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     // then one per further MSAA sample
     std::vector<FrameConst>& consts = consts_;
     consts.assign(1 + n_passes + (msaa_ - 1), fc);
-    for (uint32_t k = 0; k < n_sets; ++k)
+    // Which cascades of which light are drawn / cleared this frame.  A cascade no caster can reach stays cleared: it
+    // is left out of the pass (view_mask), and its layer is only cleared again if it was drawn into since.
+    std::vector<uint32_t> draw_mask(n_sets, 0u), clear_mask(n_sets, 0u);
+    for (uint32_t k = 0; k < n_sets; ++k) {
         for (uint32_t c = 0; c < kShadowCascades; ++c) {
-            FrameConst& sfc = consts[1 + k * kShadowCascades + c];
-            lights_[shadowed[k]].cascades[c].to_cols_array(sfc.pv);
-            sfc.width = sfc.height = kShadowSize; sfc.tiles_x = sfc.tiles_y = kShadowSize / kTile;
-            sfc.rank = 0; sfc.world = 1; sfc.n_lights = 0;
-            sfc.n_samples = 1; sfc.sub_dx = sfc.sub_dy = 0;      // shadow maps are single-sampled (visual_server.rs:371)
+            const bool casters = cascade_has_casters(lights_[shadowed[k]].cascades[c]);
+            if (casters) draw_mask[k] |= 1u << c;
+            if (casters || !shadow_layer_clear_[p][k][c]) clear_mask[k] |= 1u << c;
         }
+        FrameConst& sfc = consts[1 + k];
+        const Mat4* cas = lights_[shadowed[k]].cascades;
+        cas[0].to_cols_array(sfc.pv);
+        for (uint32_t c = 1; c < kShadowCascades; ++c) cas[c].to_cols_array(sfc.pv_more[c - 1]);
+        sfc.width = kShadowSize; sfc.height = kShadowCascades * kShadowSize;
+        sfc.tiles_x = kShadowSize / kTile; sfc.tiles_y = kShadowCascades * kShadowSize / kTile;
+        sfc.n_views = kShadowCascades; sfc.view_h = kShadowSize; sfc.view_mask = draw_mask[k];
+        sfc.n_units_view = fc.n_units; sfc.n_units = fc.n_units * kShadowCascades;
+        sfc.rank = 0; sfc.world = 1; sfc.n_lights = 0;
+        sfc.n_samples = 1; sfc.sub_dx = sfc.sub_dy = 0;      // shadow maps are single-sampled (visual_server.rs:371)
+    }
     for (uint32_t smp = 1; smp < msaa_; ++smp) sample_shift(smp, consts[n_passes + smp].sub_dx, consts[n_passes + smp].sub_dy);
     constexpr size_t kConstSlot = (sizeof(FrameConst) + 255) / 256 * 256;
     const size_t off_fc = align_up(off_ss + n_sets * sizeof(ShadowSet), 256);
@@ -972,32 +986,42 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         if (timed || serialize_next_) HIP_CHECK(hipStreamWaitEvent(gs, shade_done_[p ^ 1u], 0));
     }
     mark(7, gs);
-    for (uint32_t k = 0; k < n_sets; ++k)
-        for (uint32_t c = 0; c < kShadowCascades; ++c) {
-            // a cascade no caster can reach stays cleared: its eight launch-bound kernels (and a 33 MB clear) are
-            // most of a small scene's frame (C1': three of the four cascades)
-            const bool casters = cascade_has_casters(lights_[shadowed[k]].cascades[c]);
-            if (!casters && shadow_layer_clear_[p][k][c]) continue;
-            FrameBuffers sfb = fb;
-            sfb.items = reinterpret_cast<const DrawItem*>(tb + off_si); sfb.lights = nullptr; sfb.shadow_sets = nullptr; sfb.alpha_test = 0;
-            sfb.counters = bp.counters + 1 + k * kShadowCascades + c;
-            sfb.launch_order = d_shadow_order_.ptr; sfb.n_owned = kShadowTiles;
-            sfb.vis = shadow_layers_[p][k].ptr + (size_t)c * kShadowTiles * kTilePixels;
-            sfb.frame_rgba8 = nullptr; sfb.tiles_rgba8 = nullptr; sfb.packed = nullptr; sfb.hdr = nullptr;
-            const FrameConst& sfc = consts[1 + k * kShadowCascades + c];
-            sfb.frame_const = const_slot(1 + k * kShadowCascades + c);
-            clear(sfb, sfc);
-            counter_set_ran_[1 + k * kShadowCascades + c] = 1;
-            shadow_layer_clear_[p][k][c] = !casters;
-            if (!casters) continue;
-            launch_cull(sfb, sfc, gs);
-            launch_transform(sfb, sfc, gs);
-            launch_setup(sfb, sfc, cap_, gs);
-            launch_clip(sfb, sfc, cap_, gs);
-            launch_scan(sfb, sfc, cap_, gs);
-            launch_bin(sfb, sfc, cap_, gs);
-            launch_raster(sfb, sfc, cap_, gs);
+    for (uint32_t k = 0; k < n_sets; ++k) {
+        // a cascade no caster can reach stays cleared and out of the pass: its share of the launch-bound kernels (and a
+        // 33 MB clear) was most of a small scene's frame (C1': three of the four cascades)
+        if (!clear_mask[k]) continue;
+        DeviceBuffer<TileRef>& order = d_shadow_order_[clear_mask[k]];
+        const uint32_t n_order = (uint32_t)__builtin_popcount(clear_mask[k]) * kShadowTiles;
+        if (!order.ptr) {
+            std::vector<TileRef> list;
+            list.reserve(n_order);
+            for (uint32_t c = 0; c < kShadowCascades; ++c)
+                if ((clear_mask[k] >> c) & 1u)
+                    for (uint32_t t = 0; t < kShadowTiles; ++t) list.push_back(TileRef{c * kShadowTiles + t, c * kShadowTiles + t});
+            order.ensure(n_order);
+            HIP_CHECK(hipMemcpy(order.ptr, list.data(), n_order * sizeof(TileRef), hipMemcpyHostToDevice));
         }
+        FrameBuffers sfb = fb;
+        sfb.items = reinterpret_cast<const DrawItem*>(tb + off_si); sfb.lights = nullptr; sfb.shadow_sets = nullptr; sfb.alpha_test = 0;
+        sfb.counters = bp.counters + 1 + k;
+        sfb.launch_order = order.ptr; sfb.n_owned = n_order;
+        sfb.vis = shadow_layers_[p][k].ptr;         // the four layers, contiguous: the stacked target's tiles
+        sfb.frame_rgba8 = nullptr; sfb.tiles_rgba8 = nullptr; sfb.packed = nullptr; sfb.hdr = nullptr;
+        const FrameConst& sfc = consts[1 + k];
+        sfb.frame_const = const_slot(1 + k);
+        clear(sfb, sfc);
+        counter_set_ran_[1 + k] = 1;
+        for (uint32_t c = 0; c < kShadowCascades; ++c)
+            if ((clear_mask[k] >> c) & 1u) shadow_layer_clear_[p][k][c] = !((draw_mask[k] >> c) & 1u);
+        if (!draw_mask[k]) continue;
+        launch_cull(sfb, sfc, gs);
+        launch_transform(sfb, sfc, gs);
+        launch_setup(sfb, sfc, cap_, gs);
+        launch_clip(sfb, sfc, cap_, gs);
+        launch_scan(sfb, sfc, cap_, gs);
+        launch_bin(sfb, sfc, cap_, gs);
+        launch_raster(sfb, sfc, cap_, gs);
+    }
     mark(0, gs);
     counter_set_ran_[0] = 1;
     clear(fb, fc);                      // visibility words, tile counts, vertex-block flags, frame counters
@@ -1086,7 +1110,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
             add(dims, sizeof dims);
         }
         for (uint32_t k = 0; k < n_sets; ++k) { const void* lp = shadow_layers_[p][k].ptr; add(&lp, sizeof lp); }
-        const void* ptrs[8] = {bp.counters, bp.vis, d_hdr_.ptr, d_present_.ptr, d_shadow_order_.ptr, tb, h, reinterpret_cast<const void*>(total)};
+        const void* ptrs[8] = {bp.counters, bp.vis, d_hdr_.ptr, d_present_.ptr, nullptr, tb, h, reinterpret_cast<const void*>(total)};
         add(ptrs, sizeof ptrs);
         const uint64_t misc[10] = {off_si, off_fc, n_sets, msaa_, surface_w_, surface_h_, width_, height_, tone_mapping_, render_size_factor_ > 1.0f ? 1u : 0u};
         add(misc, sizeof misc);

@@ -265,7 +265,7 @@ private:
     DeviceBuffer<FrameCounters> d_counters_[2];     // [0] main pass, then one per shadow pass
     uint32_t n_counter_sets_ = 1, h_counter_sets_ = 0;
     // shadow cascades of the directional lights
-    DeviceBuffer<TileRef> d_shadow_order_;
+    DeviceBuffer<TileRef> d_shadow_order_[16];      // per mask of cascades: the tiles of those layers in the stacked target
     std::vector<std::array<bool, 4>> shadow_layer_clear_[2];     // the layer holds nothing but the clear value (a cascade without casters is not rendered again)
     bool cascade_has_casters(const Mat4& cascade) const;
     std::vector<DeviceBuffer<uint64_t>> shadow_layers_[2];   // per frame parity and shadowed light: kShadowCascades visibility buffers
