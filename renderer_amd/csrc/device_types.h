@@ -93,11 +93,12 @@ struct ShadowSet {
     const uint64_t* layers[kShadowCascades];
 };
 
-// One registered texture as the shading kernel samples it: every mip level as RGBA f32 (rgb already
-// through the sRGB EOTF — the reference's Rgba8UnormSrgb view, backend.rs:376), levels packed
-// largest first, level l being max(1, width >> l) x max(1, height >> l).
+// One registered texture as the shading kernel samples it: every mip level as the caller's RGBA8 bytes (sRGB-encoded
+// colour, linear alpha: the reference's Rgba8UnormSrgb texture, backend.rs:365-383), decoded at the tap through a
+// 512-entry table; levels packed largest first, level l being max(1, width >> l) x max(1, height >> l).
+// (The font atlas of the 2D pass uses the same descriptor over RGBA f32 texels.)
 struct TextureDesc {
-    const float* texels;
+    const void* texels;
     uint32_t width, height, mips;
     uint32_t opaque;                // every texel alpha == 1
 };

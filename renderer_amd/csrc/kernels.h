@@ -20,6 +20,7 @@ struct FrameBuffers {
     const GpuLight* lights;
     const ShadowSet* shadow_sets;   // indexed by GpuLight::shadow_index
     const TextureDesc* textures;    // indexed by DrawItem::texture
+    const float* srgb_lut;          // 512 entries: [0,256) sRGB8 -> linear, [256,512) alpha8 -> [0,1]
     uint32_t alpha_test;            // some draw item has kItemAlphaTest: launch the raster variants with the test
     uint32_t has_textures;          // some draw item is textured: launch the full shading variant
     const uint32_t* unit_bases;     // n_items + 1: first work unit of each item

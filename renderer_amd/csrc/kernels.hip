@@ -361,7 +361,26 @@ constexpr uint32_t kSmallPixels = 16;
 // textureSample with the reference's "filtered" sampler (backend.rs:414-426: Repeat, linear
 // mag/min/mip), restated isotropically as in the oracle: rho = longer pixel footprint in texels,
 // lambda = log2(rho) clamped to [0, mips-1], bilinear taps at floor(x - 0.5), two levels blended.
-__device__ __forceinline__ f32x4 texture_bilinear(const TextureDesc& t, uint32_t level, float u, float v) {
+// Texel fetchers.  Registered textures are kept as the caller's RGBA8 bytes (4 B per texel, as the reference uploads
+// them: backend.rs:365-383) and decoded at the tap through a 512-entry table: [0, 256) the sRGB EOTF (the
+// Rgba8UnormSrgb view, evaluated in f64 and rounded once), [256, 512) alpha / 255 — the values the RGBA f32 copy
+// of round 1 held, at a quarter of its footprint and tap bytes.  The font atlas of the 2D pass stays RGBA f32.
+struct FetchF32 {
+    gptr_f32x4 base;
+    __device__ __forceinline__ f32x4 operator()(size_t k) const { return base[k]; }
+};
+template <class Lut>
+struct FetchSrgb8 {
+    gptr_u32 base;
+    Lut lut;
+    __device__ __forceinline__ f32x4 operator()(size_t k) const {
+        const uint32_t p = base[k];
+        return (f32x4){lut[p & 255u], lut[(p >> 8) & 255u], lut[(p >> 16) & 255u], lut[256u + (p >> 24)]};
+    }
+};
+
+template <class Fetch>
+__device__ __forceinline__ f32x4 texture_bilinear(const TextureDesc& t, uint32_t level, float u, float v, const Fetch& fetch_level0) {
     const uint32_t wl = max(1u, t.width >> level), hl = max(1u, t.height >> level);
     size_t off = 0;
     for (uint32_t l = 0; l < level; ++l) off += (size_t)max(1u, t.width >> l) * max(1u, t.height >> l);
@@ -373,23 +392,25 @@ __device__ __forceinline__ f32x4 texture_bilinear(const TextureDesc& t, uint32_t
         return (uint32_t)(k < 0 ? k + (long long)n : k);
     };
     const uint32_t x0 = wrap(xf, wl), x1 = wrap(xf + 1.0f, wl), y0 = wrap(yf, hl), y1 = wrap(yf + 1.0f, hl);
-    gptr_f32x4 base = (gptr_f32x4)t.texels + off;
-    const f32x4 t00 = base[(size_t)y0 * wl + x0], t10 = base[(size_t)y0 * wl + x1];
-    const f32x4 t01 = base[(size_t)y1 * wl + x0], t11 = base[(size_t)y1 * wl + x1];
+    const f32x4 t00 = fetch_level0(off + (size_t)y0 * wl + x0), t10 = fetch_level0(off + (size_t)y0 * wl + x1);
+    const f32x4 t01 = fetch_level0(off + (size_t)y1 * wl + x0), t11 = fetch_level0(off + (size_t)y1 * wl + x1);
     const f32x4 top = t00 * (1.0f - fx) + t10 * fx, bot = t01 * (1.0f - fx) + t11 * fx;
     return top * (1.0f - fy) + bot * fy;
 }
-__device__ __forceinline__ f32x4 texture_sample(const TextureDesc& t, float u, float v, float dudx, float dvdx,
+// `lut`: the 512-entry decode table (global memory, or the shading kernel's copy in LDS)
+template <class Lut>
+__device__ __forceinline__ f32x4 texture_sample(const TextureDesc& t, Lut lut, float u, float v, float dudx, float dvdx,
                                                 float dudy, float dvdy) {
+    const FetchSrgb8<Lut> fetch{(gptr_u32)t.texels, lut};
     const float ax = dudx * (float)t.width, ay = dvdx * (float)t.height, bx = dudy * (float)t.width, by = dvdy * (float)t.height;
     const float rho2 = fmaxf(ax * ax + ay * ay, bx * bx + by * by);
     float lambda = 0.5f * log2f(rho2);
     lambda = (lambda != lambda) ? 0.0f : fminf(fmaxf(lambda, 0.0f), (float)(t.mips - 1u));
     const float lf = floorf(lambda), frac = lambda - lf;
     const uint32_t l0 = (uint32_t)lf, l1 = min(l0 + 1u, t.mips - 1u);
-    f32x4 a = texture_bilinear(t, l0, u, v);
+    f32x4 a = texture_bilinear(t, l0, u, v, fetch);
     if (frac > 0.0f) {
-        const f32x4 b = texture_bilinear(t, l1, u, v);
+        const f32x4 b = texture_bilinear(t, l1, u, v, fetch);
         a = a * (1.0f - frac) + b * frac;
     }
     return a;
@@ -433,7 +454,7 @@ __device__ __forceinline__ bool alpha_pass(const FrameBuffers& fb, FrameConstRef
     const float uu = (b0 * u0 + b1 * u1) + b2 * u2, vv = (b0 * v0 + b1 * v1) + b2 * v2;
     const float dudx = (dx0 * u0 + dx1 * u1) + dx2 * u2, dvdx = (dx0 * v0 + dx1 * v1) + dx2 * v2;
     const float dudy = (dy0 * u0 + dy1 * u1) + dy2 * u2, dvdy = (dy0 * v0 + dy1 * v1) + dy2 * v2;
-    const f32x4 texel = texture_sample(fb.textures[tex], uu, vv, dudx, dvdx, dudy, dvdy);
+    const f32x4 texel = texture_sample(fb.textures[tex], (gptr_f32)fb.srgb_lut, uu, vv, dudx, dvdx, dudy, dvdy);
     return !(d.base_color[3] * texel.w < 0.5f);
 }
 
@@ -1317,7 +1338,7 @@ struct PixelInputs {
 // through scalar loads; per pixel only the index triple and the three 32-byte vertices are gathered.
 template <bool kTextures>
 __device__ __forceinline__ void prepare_pixel(const DrawItem& d, FrameConstRef fc, const float4* __restrict__ clip,
-                                              const TextureDesc* __restrict__ textures, uint32_t id, uint32_t i,
+                                              const TextureDesc* __restrict__ textures, const float* lut, uint32_t id, uint32_t i,
                                               uint32_t j, PixelInputs& o, FrameCounters* counters) {
     // straight-line: an index that would leave its buffer is clamped and reported, not branched on
     uint32_t t = id - d.tri_base;
@@ -1413,7 +1434,7 @@ __device__ __forceinline__ void prepare_pixel(const DrawItem& d, FrameConstRef f
         if (!(fabsf(dx0) + fabsf(dx1) + fabsf(dx2) + fabsf(dy0) + fabsf(dy1) + fabsf(dy2) < 3.0e38f)) dx0 = dx1 = dx2 = dy0 = dy1 = dy2 = 0.0f;
         const float dudx = (dx0 * u0 + dx1 * u1) + dx2 * u2, dvdx = (dx0 * v0 + dx1 * v1) + dx2 * v2;
         const float dudy = (dy0 * u0 + dy1 * u1) + dy2 * u2, dvdy = (dy0 * v0 + dy1 * v1) + dy2 * v2;
-        const f32x4 texel = texture_sample(textures[d.texture], uu, vv, dudx, dvdx, dudy, dvdy);
+        const f32x4 texel = texture_sample(textures[d.texture], lut, uu, vv, dudx, dvdx, dudy, dvdy);
         tr = texel.x; tg = texel.y; tb = texel.z;
     }
     o.br = d.base_color[0] * tr; o.bg = d.base_color[1] * tg; o.bb = d.base_color[2] * tb;
@@ -1594,7 +1615,9 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(
     static_assert(kSamples == 1 || PPT == 1, "the MSAA variant shades one pixel per lane");
     __shared__ GpuLight s_lights[kMaxLights];
     __shared__ uint32_t s_bases[kLdsItems + 1];
+    __shared__ float s_lut[kShadows ? 512 : 1];     // texel decode table (see FetchSrgb8), full variant only
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if constexpr (kShadows) { s_lut[tid] = fb.srgb_lut[tid]; s_lut[256u + tid] = fb.srgb_lut[256u + tid]; }
     const bool bases_in_lds = fc.n_items <= kLdsItems;
     if (bases_in_lds)
         for (uint32_t k = tid; k <= fc.n_items; k += 256u) s_bases[k] = fb.tri_bases[k];
@@ -1667,7 +1690,7 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(
             if (__ballot(covered[k] && it != lead) == 0ull) {
                 // the usual case: every covered pixel of the wave belongs to one draw item
                 const DrawItem d = load_item_uniform(fb.items, lead_s);
-                if (covered[k]) prepare_pixel<kShadows>(d, fc, fb.clip, fb.textures, id, i, j, fresh, fb.counters);
+                if (covered[k]) prepare_pixel<kShadows>(d, fc, fb.clip, fb.textures, s_lut, id, i, j, fresh, fb.counters);
             } else if (covered[k]) {
                 // waterfall: one pass per distinct draw item among the wave's pixels
                 for (unsigned long long pending = __ballot(true); pending;) {
@@ -1676,7 +1699,7 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(
                     pending &= ~__ballot(mine);
                     if (mine) {
                         const DrawItem d = load_item_uniform(fb.items, cur_s);
-                        prepare_pixel<kShadows>(d, fc, fb.clip, fb.textures, id, i, j, fresh, fb.counters);
+                        prepare_pixel<kShadows>(d, fc, fb.clip, fb.textures, s_lut, id, i, j, fresh, fb.counters);
                     }
                 }
             }
@@ -1950,7 +1973,7 @@ __global__ __launch_bounds__(256) void k_overlay(OverlayParams p) {
                     const float cell = 1.0f / 128.0f;
                     const float u0 = (0.0f / 128.0f) + (float)r.glyph * cell, u1 = (1.0f / 128.0f) + (float)r.glyph * cell;
                     const float tu = u0 + (u1 - u0) * u;
-                    const f32x4 sd = texture_bilinear(p.font, 0u, tu, v);
+                    const f32x4 sd = texture_bilinear(p.font, 0u, tu, v, FetchF32{(gptr_f32x4)p.font.texels});
                     const float ratio = (r.font_size - 12.0f) / (24.0f - 12.0f);
                     const float smoothing = fminf(fmaxf(0.25f + ratio * (0.15f - 0.25f), 0.1f), 0.9f);
                     const float fill_dist = smoothstep_f(0.37f - smoothing, 0.37f + smoothing, sd.z);

@@ -116,12 +116,14 @@ VisualServer::VisualServer(uint32_t width, uint32_t height, int device) : device
     // font texture default (visual_server.rs:82) and the sRGB decode table of the 2D blends
     static const uint8_t yellow[4] = {255, 255, 0, 255};
     set_font_image(1, 1, yellow);
-    float lut[256];
+    // [0, 256): sRGB EOTF in f64, rounded once (the 2D blends and the texel decode); [256, 512): alpha / 255
+    float lut[512];
     for (int v = 0; v < 256; ++v) {
         const double c = v / 255.0;
         lut[v] = (float)(c <= 0.04045 ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4));
+        lut[256 + v] = (float)(v / 255.0);
     }
-    d_srgb_lut_.ensure(256);
+    d_srgb_lut_.ensure(512);
     HIP_CHECK(hipMemcpy(d_srgb_lut_.ptr, lut, sizeof lut, hipMemcpyHostToDevice));
 }
 
@@ -319,11 +321,11 @@ void VisualServer::register_material(uint32_t id, const Material& m) {
     if (m.texture != RND_NONE && !textures_.count(m.texture)) throw Error(RND_ERR_UNKNOWN_ID, "texture id not registered");
     materials_[id] = m;
 }
-// register_texture / update_texture (visual_server.rs:752-769): an Rgba8UnormSrgb texture with the
-// caller's mip chain (backend.rs:358-383).  Stored decoded: RGBA f32 per texel, rgb through the sRGB
-// EOTF (evaluated in f64, rounded once), so the shading kernel filters linear values as the
-// hardware sampler does.  A texture with any alpha below 255 marks the draw items that use it for the
-// per-fragment alpha test (render_mesh.wgsl:91) in the raster stage.
+// register_texture / update_texture (visual_server.rs:752-769): an Rgba8UnormSrgb texture with the caller's mip
+// chain (backend.rs:358-383).  Stored as uploaded, 4 bytes per texel; the shading kernel decodes at the tap through
+// the 512-entry table (sRGB EOTF in f64 rounded once; alpha / 255), so it filters linear values as the hardware
+// sampler does.  A texture with any alpha below 255 marks the draw items that use it for the per-fragment alpha test
+// (render_mesh.wgsl:91) in the raster stage.
 void VisualServer::register_texture(uint32_t id, uint32_t w, uint32_t h, uint32_t mips, const uint8_t* data) {
     if (id == RND_NONE || !w || !h || !mips || !data || w > 16384 || h > 16384) throw Error(RND_ERR_INVALID, "bad texture");
     uint32_t max_levels = 1;
@@ -331,26 +333,14 @@ void VisualServer::register_texture(uint32_t id, uint32_t w, uint32_t h, uint32_
     if (mips > max_levels) throw Error(RND_ERR_INVALID, "more mip levels than the size allows");
     size_t total = 0;
     for (uint32_t l = 0; l < mips; ++l) total += (size_t)std::max(1u, w >> l) * std::max(1u, h >> l);
-    std::vector<float> texels(total * 4);
-    double lut[256];
-    for (int v = 0; v < 256; ++v) {
-        const double c = v / 255.0;
-        lut[v] = c <= 0.04045 ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4);
-    }
     bool opaque = true;
-    for (size_t k = 0; k < total; ++k) {
-        texels[4 * k + 0] = (float)lut[data[4 * k + 0]];
-        texels[4 * k + 1] = (float)lut[data[4 * k + 1]];
-        texels[4 * k + 2] = (float)lut[data[4 * k + 2]];
-        texels[4 * k + 3] = (float)(data[4 * k + 3] / 255.0);
-        opaque = opaque && data[4 * k + 3] == 255;
-    }
+    for (size_t k = 0; k < total; ++k) opaque = opaque && data[4 * k + 3] == 255;
     use_device();
     finish();
     RenderTexture& t = textures_[id];
     const bool is_new = t.mips == 0;
-    t.texels.ensure(texels.size());
-    HIP_CHECK(hipMemcpy(t.texels.ptr, texels.data(), texels.size() * sizeof(float), hipMemcpyHostToDevice));
+    t.texels.ensure(total * 4);
+    HIP_CHECK(hipMemcpy(t.texels.ptr, data, total * 4, hipMemcpyHostToDevice));
     t.width = w; t.height = h; t.mips = mips; t.opaque = opaque;
     if (is_new) t.slot = (uint32_t)textures_.size() - 1;
     upload_texture_table();
@@ -916,7 +906,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     fb.frame_const = const_slot(0);
     fb.items = reinterpret_cast<const DrawItem*>(tb + off_items); fb.vert_bases = reinterpret_cast<const uint32_t*>(tb + off_vb);
     fb.tri_bases = reinterpret_cast<const uint32_t*>(tb + off_tb); fb.lights = reinterpret_cast<const GpuLight*>(tb + off_li);
-    fb.textures = d_textures_.ptr;
+    fb.textures = d_textures_.ptr; fb.srgb_lut = d_srgb_lut_.ptr;
     fb.alpha_test = frame_alpha_test_ ? 1u : 0u;
     fb.has_textures = frame_textured_ ? 1u : 0u;
     fb.shadow_sets = n_sets ? reinterpret_cast<const ShadowSet*>(tb + off_ss) : nullptr;      // null selects the shading kernel without the lookup

@@ -63,8 +63,8 @@ struct RenderSubmesh {           // visual_server.rs:948-953
     float box_lo[3] = {0, 0, 0}, box_hi[3] = {0, 0, 0};   // object-space bounds (infinite on an axis with a non-finite coordinate)
 };
 struct RenderMesh { std::vector<RenderSubmesh> submeshes; };
-struct RenderTexture {           // RenderScene::textures (visual_server.rs:901) as decoded RGBA f32 levels
-    DeviceBuffer<float> texels;
+struct RenderTexture {           // RenderScene::textures (visual_server.rs:901): RGBA8 levels, decoded at the tap
+    DeviceBuffer<uint8_t> texels;        // the caller's RGBA8 mip chain, 4 B per texel
     uint32_t width = 0, height = 0, mips = 0;
     uint32_t slot = 0;           // index into the device texture table
     bool opaque = true;          // every alpha == 255
