@@ -151,15 +151,17 @@ __device__ __forceinline__ float4 clip_position(const DrawItem& d, cptr_f32 p, f
 // link by the kernel itself) to the device block `dst` that every later kernel of the frame reads.
 // That replaces a hipMemcpyAsync (a blit kernel of its own, ~3 us plus its dependency gaps per
 // frame).  The sizes come in as arguments: the frame's constants are part of what is being copied.
-__global__ __launch_bounds__(256) void k_clear(FrameBuffers fb, uint32_t n_counts, uint32_t n_vblocks,
+__global__ __launch_bounds__(256) void k_clear(FrameBuffers fb, uint32_t n_counts, uint32_t n_vblocks, uint32_t n_planes,
                                                const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t n_vec) {
     for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n_vec; k += gridDim.x * 256u) dst[k] = src[k];
     if (blockIdx.x < fb.n_owned) {
         const uint32_t tile = fb.launch_order[blockIdx.x].tile;
         typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-        u64x2* dst = reinterpret_cast<u64x2*>(fb.vis + (size_t)tile * kTilePixels);
         const u64x2 clear = {kClearKey, kClearKey};
-        for (uint32_t k = threadIdx.x; k < kTilePixels / 2; k += 256u) dst[k] = clear;
+        for (uint32_t smp = 0; smp < n_planes; ++smp) {          // (MSAA: one plane per sample)
+            u64x2* dst = reinterpret_cast<u64x2*>(fb.vis + (size_t)smp * fb.vis_stride + (size_t)tile * kTilePixels);
+            for (uint32_t k = threadIdx.x; k < kTilePixels / 2; k += 256u) dst[k] = clear;
+        }
     }
     for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n_counts; k += gridDim.x * 256u) fb.tile_count[k] = 0;
     for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n_vblocks; k += gridDim.x * 256u) fb.vblock_needed[k] = 0;
@@ -240,6 +242,7 @@ __global__ __launch_bounds__(256) void k_cull(FrameBuffers fb) {
     }
 }
 
+constexpr int32_t kSamplePad = 96;      // MSAA x4: the samples sit up to this many sub-pixel steps from the pixel centre
 struct Snapped { int32_t x, y; float z; };
 __device__ __forceinline__ bool snap_vertex(float cx, float cy, float cz, float cw, float half_w,
                                             float half_h, Snapped& s, int32_t sub_dx, int32_t sub_dy);
@@ -327,11 +330,13 @@ __device__ __forceinline__ bool make_record(const Snapped& a, const Snapped& b, 
     // here became nested branches that each re-initialized the caller's outputs)
     int32_t xmin = min(a.x, min(b.x, c.x)), xmax = max(a.x, max(b.x, c.x));
     int32_t ymin = min(a.y, min(b.y, c.y)), ymax = max(a.y, max(b.y, c.y));
-    // pixel centres i*256+128 inside the closed bbox
-    int32_t i0 = max((xmin - kSub / 2 + kSub - 1) >> kSubpixelBits, 0);
-    int32_t i1 = min((xmax - kSub / 2) >> kSubpixelBits, (int32_t)fc.width - 1);
-    int32_t j0 = max((ymin - kSub / 2 + kSub - 1) >> kSubpixelBits, j_lo);
-    int32_t j1 = min((ymax - kSub / 2) >> kSubpixelBits, j_hi);
+    // pixel centres i*256+128 inside the closed bbox; with MSAA, pixels with any sample position inside it
+    // (the samples sit up to kSamplePad sub-pixel steps from the centre)
+    const int32_t pad = fc.n_samples > 1u ? kSamplePad : 0;
+    int32_t i0 = max((xmin - pad - kSub / 2 + kSub - 1) >> kSubpixelBits, 0);
+    int32_t i1 = min((xmax + pad - kSub / 2) >> kSubpixelBits, (int32_t)fc.width - 1);
+    int32_t j0 = max((ymin - pad - kSub / 2 + kSub - 1) >> kSubpixelBits, j_lo);
+    int32_t j1 = min((ymax + pad - kSub / 2) >> kSubpixelBits, j_hi);
     r.x0 = a.x; r.y0 = a.y; r.x1 = b.x; r.y1 = b.y; r.x2 = c.x; r.y2 = c.y;
     r.z0 = a.z; r.dz1 = b.z - a.z; r.dz2 = c.z - a.z;
     r.inv_area = 1.0f / (float)area2;
@@ -459,29 +464,65 @@ __device__ __forceinline__ bool alpha_pass(const FrameBuffers& fb, FrameConstRef
 }
 
 // fragment sinks: where a covered sample's (depth, triangle id) key is min-resolved
+// (`smp`: the MSAA sample whose plane takes the fragment; 0 without MSAA)
 struct LdsSink {
-    unsigned long long* s_vis;
+    unsigned long long* s_vis;          // kTilePixels words per sample plane
     int32_t tile_x0, tile_y0;
-    __device__ __forceinline__ void operator()(int32_t i, int32_t j, float z, uint32_t id) const {
+    __device__ __forceinline__ void operator()(int32_t i, int32_t j, float z, uint32_t id, uint32_t smp = 0) const {
         z = fminf(fmaxf(z, 0.0f), 1.0f);
         if (z < 1.0f) {
             unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | id;
-            atomicMin(&s_vis[(uint32_t)((j - tile_y0) * (int32_t)kTile + (i - tile_x0))], key);
+            atomicMin(&s_vis[smp * kTilePixels + (uint32_t)((j - tile_y0) * (int32_t)kTile + (i - tile_x0))], key);
         }
     }
 };
+
+// MSAA x4, one geometry pass: the standard pattern's sample positions relative to the pixel centre, in sub-pixel
+// steps: (-32,-96) (96,-32) (-96,32) (32,96), i.e. samples 3 and 2 mirror samples 0 and 1.  An edge function
+// F = ex*(py - y) - ey*(px - x) moves by ex*dy - ey*dx from the centre to a sample: exact integers, the values the
+// per-sample passes of round 1 got by shifting the geometry instead.
+template <class W>
+struct SampleSteps {
+    W a0, a1, a2, b0, b1, b2;           // per edge: step to sample 0 (a) and to sample 1 (b); samples 3 / 2 take -a / -b
+};
+// (W = int32_t for records below 64 px, whose edge coefficients are below 2^14; int64 otherwise)
+template <class W>
+__device__ __forceinline__ SampleSteps<W> sample_steps(int32_t ex0, int32_t ey0, int32_t ex1, int32_t ey1, int32_t ex2, int32_t ey2) {
+    return SampleSteps<W>{(W)ex0 * -96 - (W)ey0 * -32, (W)ex1 * -96 - (W)ey1 * -32, (W)ex2 * -96 - (W)ey2 * -32,
+                          (W)ex0 * -32 - (W)ey0 * 96, (W)ex1 * -32 - (W)ey1 * 96, (W)ex2 * -32 - (W)ey2 * 96};
+}
+// The fragments of one pixel whose centre has edge values w0..w2: the centre itself, or the four samples.
+// `pass()` is the per-pixel alpha test (evaluated once, only if some sample is covered).
+template <int kSamples, class W, class Pass, class Emit>
+__device__ __forceinline__ void pixel_samples(W w0, W w1, W w2, W b0, W b1, W b2, const SampleSteps<W>& st, Pass&& pass, Emit&& emit) {
+    if constexpr (kSamples == 1) {
+        if (w0 >= b0 && w1 >= b1 && w2 >= b2 && pass()) emit(w1, w2, 0u);
+    } else {
+        const W s0[4] = {w0 + st.a0, w0 + st.b0, w0 - st.b0, w0 - st.a0};
+        const W s1[4] = {w1 + st.a1, w1 + st.b1, w1 - st.b1, w1 - st.a1};
+        const W s2[4] = {w2 + st.a2, w2 + st.b2, w2 - st.b2, w2 - st.a2};
+        bool in[4], any = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { in[k] = s0[k] >= b0 && s1[k] >= b1 && s2[k] >= b2; any = any || in[k]; }
+        if (any && pass()) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (in[k]) emit(s1[k], s2[k], (uint32_t)k);
+        }
+    }
+}
 
 // straight into the tile-major visibility buffer in HBM (no-return 64-bit min at the L2): the
 // path of the triangles that cover a handful of pixels, which never enter a bin
 struct GlobalSink {
     unsigned long long* vis;
     uint32_t tiles_x, rank, world;
-    __device__ __forceinline__ void operator()(int32_t i, int32_t j, float z, uint32_t id) const {
+    uint64_t plane_stride;              // words between the planes of consecutive MSAA samples
+    __device__ __forceinline__ void operator()(int32_t i, int32_t j, float z, uint32_t id, uint32_t smp = 0) const {
         z = fminf(fmaxf(z, 0.0f), 1.0f);
         const uint32_t tx = (uint32_t)i / kTile, ty = (uint32_t)j / kTile;
         if (z < 1.0f && owns_tile(tx, ty, rank, world)) {
             unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | id;
-            const size_t at = (size_t)(ty * tiles_x + tx) * kTilePixels + (((uint32_t)j % kTile) * kTile + ((uint32_t)i % kTile));
+            const size_t at = (size_t)smp * plane_stride + (size_t)(ty * tiles_x + tx) * kTilePixels + (((uint32_t)j % kTile) * kTile + ((uint32_t)i % kTile));
 #if RND_EARLY_Z
             // early test with a plain (possibly stale) load: the word only ever decreases, so a stale
             // value can cause a redundant atomic, never a skipped one
@@ -492,7 +533,7 @@ struct GlobalSink {
     }
 };
 
-template <bool kAlpha, class Sink>
+template <bool kAlpha, int kSamples, class Sink>
 __device__ __forceinline__ void raster_small(const SetupRecord& r, int32_t i0, int32_t i1, int32_t j0, int32_t j1,
                                              const Sink& sink, const FrameBuffers& fb, FrameConstRef fc) {
     // inside-positive edges: w0 = F(v2,v1,p), w1 = F(v0,v2,p), w2 = F(v1,v0,p)
@@ -508,16 +549,17 @@ __device__ __forceinline__ void raster_small(const SetupRecord& r, int32_t i0, i
     int32_t r0 = __mul24(ex0, py - r.y2) - __mul24(ey0, px - r.x2);
     int32_t r1 = __mul24(ex1, py - r.y0) - __mul24(ey1, px - r.x0);
     int32_t r2 = __mul24(ex2, py - r.y1) - __mul24(ey2, px - r.x1);
+    const SampleSteps<int32_t> st = sample_steps<int32_t>(ex0, ey0, ex1, ey1, ex2, ey2);
     for (int32_t j = j0; j <= j1; ++j) {
         int32_t w0 = r0, w1 = r1, w2 = r2;
         for (int32_t i = i0; i <= i1; ++i) {
-            if (w0 >= b0 && w1 >= b1 && w2 >= b2) {
-                float l1 = (float)w1 * r.inv_area, l2 = (float)w2 * r.inv_area;
-                float z = (l1 * r.dz1 + l2 * r.dz2) + r.z0;
-                bool pass = true;
-                if constexpr (kAlpha) pass = !(r.flags & 2u) || alpha_pass(fb, fc, r.tri_id, (uint32_t)i, (uint32_t)j);
-                if (pass) sink(i, j, z, r.tri_id);
-            }
+            pixel_samples<kSamples, int32_t>(w0, w1, w2, b0, b1, b2, st,
+                [&] { if constexpr (kAlpha) return !(r.flags & 2u) || alpha_pass(fb, fc, r.tri_id, (uint32_t)i, (uint32_t)j); return true; },
+                [&](int32_t s1, int32_t s2, uint32_t smp) {
+                    float l1 = (float)s1 * r.inv_area, l2 = (float)s2 * r.inv_area;
+                    float z = (l1 * r.dz1 + l2 * r.dz2) + r.z0;
+                    sink(i, j, z, r.tri_id, smp);
+                });
             w0 -= ey0 * kSub; w1 -= ey1 * kSub; w2 -= ey2 * kSub;
         }
         r0 += ex0 * kSub; r1 += ex1 * kSub; r2 += ex2 * kSub;
@@ -644,11 +686,14 @@ struct DirectTri {                  // 20 dwords = 5 x 16 B
     uint32_t id;
     uint32_t origin;                // i0 | j0 << 16
     float inv_w;                    // 1 / bbox width
-    uint32_t pad[3];
+    uint32_t smp;                   // MSAA, k_setup's direct path: the one sample this entry resolves (its plane); else 0
+    uint32_t pad[2];
 };
 static_assert(sizeof(DirectTri) == 80, "DirectTri is 5 x 16 bytes");
 
-__device__ __forceinline__ DirectTri make_direct(const SetupRecord& r, const TileRect& t) {
+// smp < 0: the edge values are those of the bbox's first pixel CENTRE; smp >= 0 (MSAA, k_setup's direct path): of
+// MSAA sample `smp` of that pixel, and `t` is that sample's own pixel range
+__device__ __forceinline__ DirectTri make_direct(const SetupRecord& r, const TileRect& t, int smp = -1) {
     // same integers as raster_small (bbox below 64 px: every factor fits 24 bits)
     const int32_t ex0 = r.x1 - r.x2, ey0 = r.y1 - r.y2;
     const int32_t ex1 = r.x2 - r.x0, ey1 = r.y2 - r.y0;
@@ -669,12 +714,19 @@ __device__ __forceinline__ DirectTri make_direct(const SetupRecord& r, const Til
     d.id = r.tri_id;
     d.origin = (uint32_t)t.i0 | ((uint32_t)t.j0 << 16);
     d.inv_w = __builtin_amdgcn_rcpf((float)w);
-    d.pad[0] = d.pad[1] = d.pad[2] = 0;
+    d.smp = 0; d.pad[0] = d.pad[1] = 0;
+    if (smp >= 0) {
+        const SampleSteps<int32_t> st = sample_steps<int32_t>(ex0, ey0, ex1, ey1, ex2, ey2);
+        const int32_t sg = (smp & 2) ? -1 : 1;                    // samples 2, 3 mirror samples 1, 0
+        const bool use_a = smp == 0 || smp == 3;
+        d.r0 += sg * (use_a ? st.a0 : st.b0); d.r1 += sg * (use_a ? st.a1 : st.b1); d.r2 += sg * (use_a ? st.a2 : st.b2);
+        d.smp = (uint32_t)smp;
+    }
     return d;
 }
 
 // pixel k (row-major in the bbox) of a compacted triangle
-template <bool kAlpha, class Sink>
+template <bool kAlpha, int kSamples, class Sink>
 __device__ __forceinline__ void direct_pixel(const DirectTri& d, uint32_t k, const Sink& sink, const FrameBuffers& fb,
                                              FrameConstRef fc) {
     const uint32_t w = d.shape & 255u;
@@ -686,14 +738,18 @@ __device__ __forceinline__ void direct_pixel(const DirectTri& d, uint32_t k, con
     const int32_t w1 = d.r1 + __mul24((int32_t)dj, d.sx1) - __mul24((int32_t)di, d.sy1);
     const int32_t w2 = d.r2 + __mul24((int32_t)dj, d.sx2) - __mul24((int32_t)di, d.sy2);
     const int32_t b0 = (int32_t)((d.shape >> 16) & 1u), b1 = (int32_t)((d.shape >> 17) & 1u), b2 = (int32_t)((d.shape >> 18) & 1u);
-    if (w0 >= b0 && w1 >= b1 && w2 >= b2) {
-        const float l1 = (float)w1 * d.inv_area, l2 = (float)w2 * d.inv_area;
-        const float z = (l1 * d.dz1 + l2 * d.dz2) + d.z0;
-        const uint32_t i = (d.origin & 0xFFFFu) + di, j = (d.origin >> 16) + dj;
-        bool pass = true;
-        if constexpr (kAlpha) pass = !((d.shape >> 19) & 1u) || alpha_pass(fb, fc, d.id, i, j);
-        if (pass) sink((int32_t)i, (int32_t)j, z, d.id);
-    }
+    const uint32_t i = (d.origin & 0xFFFFu) + di, j = (d.origin >> 16) + dj;
+    SampleSteps<int32_t> st{};
+    if constexpr (kSamples > 1)     // (sx = ex * 256, sy = ey * 256: the shifts are exact)
+        st = sample_steps<int32_t>(d.sx0 >> kSubpixelBits, d.sy0 >> kSubpixelBits, d.sx1 >> kSubpixelBits, d.sy1 >> kSubpixelBits,
+                          d.sx2 >> kSubpixelBits, d.sy2 >> kSubpixelBits);
+    pixel_samples<kSamples, int32_t>(w0, w1, w2, b0, b1, b2, st,
+        [&] { if constexpr (kAlpha) return !((d.shape >> 19) & 1u) || alpha_pass(fb, fc, d.id, i, j); return true; },
+        [&](int32_t s1, int32_t s2, uint32_t smp) {
+            const float l1 = (float)s1 * d.inv_area, l2 = (float)s2 * d.inv_area;
+            const float z = (l1 * d.dz1 + l2 * d.dz2) + d.z0;
+            sink((int32_t)i, (int32_t)j, z, d.id, kSamples == 1 ? d.smp : smp);
+        });
 }
 
 // A triangle whose bbox holds at most fb.direct_pixels pixel centres (kDirectPixels; the bulk at C2..C5 density) is
@@ -707,7 +763,8 @@ __device__ __forceinline__ void direct_pixel(const DirectTri& d, uint32_t k, con
 // One workgroup per surviving work unit (draw item, chunk of kChunkTris triangles): the item is
 // uniform for the whole workgroup, so its fields come in through scalar loads.
 // kAlpha: some draw item of the frame takes the per-fragment texture alpha test (compiled out otherwise)
-template <bool kAlpha>
+// kSamples: 1, or 4 (MSAA): every candidate pixel is tested at its four sample positions, one visibility plane each
+template <bool kAlpha, int kSamples>
 __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) {
     FrameConstRef fc = frame_const_ref(fb.frame_const);
     __shared__ uint32_t s_used;         // record slots of this workgroup's chunk handed out so far
@@ -735,7 +792,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
     const bool tables_ok = guard(vb + nv <= fc.n_verts, fb.counters, kGuardSetup);
     const uint32_t chunk_base = blockIdx.x * chunk_tris;
     const uint32_t n_tiles = fc.tiles_x * fc.tiles_y;
-    const GlobalSink direct_sink{reinterpret_cast<unsigned long long*>(fb.vis), fc.tiles_x, fc.rank, fc.world};
+    const GlobalSink direct_sink{reinterpret_cast<unsigned long long*>(fb.vis), fc.tiles_x, fc.rank, fc.world, fb.vis_stride};
     uint32_t valid = 0;
     for (uint32_t iter = 0; iter < chunk_tris / 256u; ++iter) {
         const uint32_t local = iter * 256u + threadIdx.x;
@@ -777,17 +834,18 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
         // small triangles: rasterize now, no record
         const bool direct = emit && (rec.flags & 1u) &&
                             (uint32_t)(tr.i1 - tr.i0 + 1) * (uint32_t)(tr.j1 - tr.j0 + 1) <= fb.direct_pixels;
-        const unsigned long long dm = __ballot(direct);
-        if (dm) {
-            if (direct) {
-                const DirectTri dt = make_direct(rec, tr);
+        // the wave's direct triangles are compacted into LDS and re-dealt four lanes each
+        auto run_direct = [&](bool has, const TileRect& t, int smp) {
+            const unsigned long long dm = __ballot(has);
+            if (!dm) return;
+            if (has) {
+                const DirectTri dt = make_direct(rec, t, smp);
                 const uint4* src = reinterpret_cast<const uint4*>(&dt);
                 uint4* dst = s_direct[wave][__popcll(dm & ((1ull << lane) - 1ull))];
                 dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3]; dst[4] = src[4];
-                emit = false;
             }
             // the wave's own LDS traffic is ordered by the hardware; keep the compiler from moving the
-            // reads above the writes (and the next iteration's writes above these reads)
+            // reads above the writes (and the next round's writes above these reads)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -800,12 +858,32 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
                     const uint4* src = s_direct[wave][which];
                     dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3]; dst[4] = src[4];
                     const uint32_t npix = (dt.shape >> 8) & 255u;
-                    for (uint32_t k = lane & 3u; k < npix; k += 4u) direct_pixel<kAlpha>(dt, k, direct_sink, fb, fc);
+                    for (uint32_t k = lane & 3u; k < npix; k += 4u) direct_pixel<kAlpha, 1>(dt, k, direct_sink, fb, fc);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+        };
+        if constexpr (kSamples == 1) {
+            run_direct(direct, tr, -1);
+        } else {
+            // MSAA: one round per sample, each over the pixels whose sample `smp` lies in the bbox (a sub-pixel
+            // triangle has ~4 such pixels per sample, against 9 pixels x 4 samples when walked pixel by pixel);
+            // the triangle's set-up is shared by the four rounds
+            const int32_t xmin = min(rec.x0, min(rec.x1, rec.x2)), xmax = max(rec.x0, max(rec.x1, rec.x2));
+            const int32_t ymin = min(rec.y0, min(rec.y1, rec.y2)), ymax = max(rec.y0, max(rec.y1, rec.y2));
+#pragma unroll
+            for (int smp = 0; smp < 4; ++smp) {
+                constexpr int32_t kDx[4] = {-32, 96, -96, 32}, kDy[4] = {-96, -32, 32, 96};
+                TileRect ts = tr;
+                ts.i0 = max((xmin - kDx[smp] - kSub / 2 + kSub - 1) >> kSubpixelBits, 0);
+                ts.i1 = min((xmax - kDx[smp] - kSub / 2) >> kSubpixelBits, (int32_t)fc.width - 1);
+                ts.j0 = max((ymin - kDy[smp] - kSub / 2 + kSub - 1) >> kSubpixelBits, j_lo);
+                ts.j1 = min((ymax - kDy[smp] - kSub / 2) >> kSubpixelBits, j_hi);
+                run_direct(direct && ts.i0 <= ts.i1 && ts.j0 <= ts.j1, ts, smp);
+            }
         }
+        if (direct) emit = false;
         // the rest become records: the wave takes its slots from the workgroup's chunk with one LDS
         // atomic (the waves of a workgroup do not wait for each other)
         const unsigned long long em = __ballot(emit);
@@ -1073,7 +1151,7 @@ __global__ __launch_bounds__(256) void k_bin_fill(FrameBuffers fb, Capacities ca
 // full-rate 24-bit multiply and 32-bit sums (as in raster_small); otherwise 64-bit arithmetic.  Medium
 // triangles (tens of pixels, the bulk of real content) are narrow: with 64-bit edges this sweep was
 // 200 wave instructions per bin entry and made k_raster VALU-bound (C2 at 8K).
-template <bool kAlpha, bool kNarrow>
+template <bool kAlpha, bool kNarrow, int kSamples>
 __device__ __forceinline__ void raster_wave(const SetupRecord& r, int32_t i0, int32_t i1, int32_t j0, int32_t j1,
                                             const LdsSink& sink, const FrameBuffers& fb, FrameConstRef fc) {
     typedef typename std::conditional<kNarrow, int32_t, long long>::type edge_t;
@@ -1100,6 +1178,7 @@ __device__ __forceinline__ void raster_wave(const SetupRecord& r, int32_t i0, in
         r1 = (long long)ex1 * (py - r.y0) - (long long)ey1 * (px - r.x0);
         r2 = (long long)ex2 * (py - r.y1) - (long long)ey2 * (px - r.x1);
     }
+    const SampleSteps<edge_t> st = sample_steps<edge_t>(ex0, ey0, ex1, ey1, ex2, ey2);
     const edge_t sx0 = (edge_t)ey0 * (8 * kSub), sx1 = (edge_t)ey1 * (8 * kSub), sx2 = (edge_t)ey2 * (8 * kSub);   // per block column (subtracted)
     const edge_t sy0 = (edge_t)ex0 * (8 * kSub), sy1 = (edge_t)ex1 * (8 * kSub), sy2 = (edge_t)ex2 * (8 * kSub);   // per block row
     for (int32_t by = j0; by <= j1; by += 8) {
@@ -1107,13 +1186,14 @@ __device__ __forceinline__ void raster_wave(const SetupRecord& r, int32_t i0, in
         const int32_t j = by + ly;
         for (int32_t bx = i0; bx <= i1; bx += 8) {
             const int32_t i = bx + lx;
-            if (i <= i1 && j <= j1 && w0 >= b0 && w1 >= b1 && w2 >= b2) {
-                float l1 = (float)w1 * r.inv_area, l2 = (float)w2 * r.inv_area;
-                float z = (l1 * r.dz1 + l2 * r.dz2) + r.z0;
-                bool pass = true;
-                if constexpr (kAlpha) pass = !(r.flags & 2u) || alpha_pass(fb, fc, r.tri_id, (uint32_t)i, (uint32_t)j);
-                if (pass) sink(i, j, z, r.tri_id);
-            }
+            if (i <= i1 && j <= j1)
+                pixel_samples<kSamples, edge_t>(w0, w1, w2, b0, b1, b2, st,
+                    [&] { if constexpr (kAlpha) return !(r.flags & 2u) || alpha_pass(fb, fc, r.tri_id, (uint32_t)i, (uint32_t)j); return true; },
+                    [&](edge_t s1, edge_t s2, uint32_t smp) {
+                        float l1 = (float)s1 * r.inv_area, l2 = (float)s2 * r.inv_area;
+                        float z = (l1 * r.dz1 + l2 * r.dz2) + r.z0;
+                        sink(i, j, z, r.tri_id, smp);
+                    });
             w0 -= sx0; w1 -= sx1; w2 -= sx2;
         }
         r0 += sy0; r1 += sy1; r2 += sy2;
@@ -1128,10 +1208,10 @@ __device__ __forceinline__ SetupRecord load_record(const SetupRecord* __restrict
     return r;
 }
 
-template <bool kAlpha>
+template <bool kAlpha, int kSamples>
 __global__ __launch_bounds__(256) void k_raster(FrameBuffers fb, Capacities cap) {
     FrameConstRef fc = frame_const_ref(fb.frame_const);
-    __shared__ unsigned long long s_vis[kTilePixels];
+    __shared__ unsigned long long s_vis[kTilePixels * kSamples];        // one plane per MSAA sample
     // the batch's triangles that a whole wave sweeps, kept in LDS by the lanes that classified them: a
     // second fetch of the record per triangle from global memory made the sweep a queue of ~1 us round
     // trips (C2 at 8K, ~37 bin entries of ~70 px per tile: 13 us per tile, 0.41 ms per frame)
@@ -1172,7 +1252,10 @@ __global__ __launch_bounds__(256) void k_raster(FrameBuffers fb, Capacities cap)
     if (slice * 256u >= n_all || slice >= n_slices) return;
     const bool shared_tile = n_slices > 1u;  // several workgroups on this tile: they meet in the global words by atomic min
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(fb.vis) + (size_t)tile * kTilePixels;
-    for (uint32_t k = tid; k < kTilePixels; k += 256u) s_vis[k] = slice == 0u ? dst[k] : kClearKey;
+    constexpr int32_t pad = kSamples > 1 ? kSamplePad : 0;      // candidate pixels: any sample position inside the bbox
+#pragma unroll
+    for (uint32_t smp = 0; smp < (uint32_t)kSamples; ++smp)
+        for (uint32_t k = tid; k < kTilePixels; k += 256u) s_vis[smp * kTilePixels + k] = slice == 0u ? dst[(size_t)smp * fb.vis_stride + k] : kClearKey;
     const LdsSink sink{s_vis, tile_x0, tile_y0};
     __syncthreads();
     for (uint32_t b = slice * 256u; b < n_all; b += n_slices * 256u) {
@@ -1194,13 +1277,13 @@ __global__ __launch_bounds__(256) void k_raster(FrameBuffers fb, Capacities cap)
             SetupRecord r = load_record(fb.records, slot);
             int32_t xmin = min(r.x0, min(r.x1, r.x2)), xmax = max(r.x0, max(r.x1, r.x2));
             int32_t ymin = min(r.y0, min(r.y1, r.y2)), ymax = max(r.y0, max(r.y1, r.y2));
-            int32_t i0 = max((xmin - kSub / 2 + kSub - 1) >> kSubpixelBits, tile_x0);
-            int32_t i1 = min((xmax - kSub / 2) >> kSubpixelBits, tile_x1);
-            int32_t j0 = max((ymin - kSub / 2 + kSub - 1) >> kSubpixelBits, tile_y0);
-            int32_t j1 = min((ymax - kSub / 2) >> kSubpixelBits, tile_y1);
+            int32_t i0 = max((xmin - pad - kSub / 2 + kSub - 1) >> kSubpixelBits, tile_x0);
+            int32_t i1 = min((xmax + pad - kSub / 2) >> kSubpixelBits, tile_x1);
+            int32_t j0 = max((ymin - pad - kSub / 2 + kSub - 1) >> kSubpixelBits, tile_y0);
+            int32_t j1 = min((ymax + pad - kSub / 2) >> kSubpixelBits, tile_y1);
             if (i0 <= i1 && j0 <= j1) {
                 uint32_t npix = (uint32_t)(i1 - i0 + 1) * (uint32_t)(j1 - j0 + 1);
-                if ((r.flags & 1u) && npix <= kSmallPixels) raster_small<kAlpha>(r, i0, i1, j0, j1, sink, fb, fc);
+                if ((r.flags & 1u) && npix <= kSmallPixels) raster_small<kAlpha, kSamples>(r, i0, i1, j0, j1, sink, fb, fc);
                 else {
                     const bool medium = (r.flags & 1u) && npix <= 255u;
                     const uint32_t k = medium ? atomicAdd(&s_nmed, 1u) : 255u - atomicAdd(&s_nlarge, 1u);
@@ -1220,13 +1303,13 @@ __global__ __launch_bounds__(256) void k_raster(FrameBuffers fb, Capacities cap)
             int32_t xmin = min(r.x0, min(r.x1, r.x2)), xmax = max(r.x0, max(r.x1, r.x2));
             int32_t ymin = min(r.y0, min(r.y1, r.y2)), ymax = max(r.y0, max(r.y1, r.y2));
             TileRect tr{0, 0, 0, 0, 0, 0, 0, 0};
-            tr.i0 = max((xmin - kSub / 2 + kSub - 1) >> kSubpixelBits, tile_x0);
-            tr.i1 = min((xmax - kSub / 2) >> kSubpixelBits, tile_x1);
-            tr.j0 = max((ymin - kSub / 2 + kSub - 1) >> kSubpixelBits, tile_y0);
-            tr.j1 = min((ymax - kSub / 2) >> kSubpixelBits, tile_y1);
+            tr.i0 = max((xmin - pad - kSub / 2 + kSub - 1) >> kSubpixelBits, tile_x0);
+            tr.i1 = min((xmax + pad - kSub / 2) >> kSubpixelBits, tile_x1);
+            tr.j0 = max((ymin - pad - kSub / 2 + kSub - 1) >> kSubpixelBits, tile_y0);
+            tr.j1 = min((ymax + pad - kSub / 2) >> kSubpixelBits, tile_y1);
             const DirectTri dt = make_direct(r, tr);
             const uint32_t npix = (dt.shape >> 8) & 255u;
-            for (uint32_t k = tid % kMediumLanes; k < npix; k += kMediumLanes) direct_pixel<kAlpha>(dt, k, sink, fb, fc);
+            for (uint32_t k = tid % kMediumLanes; k < npix; k += kMediumLanes) direct_pixel<kAlpha, kSamples>(dt, k, sink, fb, fc);
         }
         for (uint32_t q = tid >> 6; q < nlarge; q += 4u) {
             SetupRecord r;
@@ -1237,22 +1320,26 @@ __global__ __launch_bounds__(256) void k_raster(FrameBuffers fb, Capacities cap)
             }
             int32_t xmin = min(r.x0, min(r.x1, r.x2)), xmax = max(r.x0, max(r.x1, r.x2));
             int32_t ymin = min(r.y0, min(r.y1, r.y2)), ymax = max(r.y0, max(r.y1, r.y2));
-            int32_t i0 = max((xmin - kSub / 2 + kSub - 1) >> kSubpixelBits, tile_x0);
-            int32_t i1 = min((xmax - kSub / 2) >> kSubpixelBits, tile_x1);
-            int32_t j0 = max((ymin - kSub / 2 + kSub - 1) >> kSubpixelBits, tile_y0);
-            int32_t j1 = min((ymax - kSub / 2) >> kSubpixelBits, tile_y1);
-            if (r.flags & 1u) raster_wave<kAlpha, true>(r, i0, i1, j0, j1, sink, fb, fc);
-            else raster_wave<kAlpha, false>(r, i0, i1, j0, j1, sink, fb, fc);
+            int32_t i0 = max((xmin - pad - kSub / 2 + kSub - 1) >> kSubpixelBits, tile_x0);
+            int32_t i1 = min((xmax + pad - kSub / 2) >> kSubpixelBits, tile_x1);
+            int32_t j0 = max((ymin - pad - kSub / 2 + kSub - 1) >> kSubpixelBits, tile_y0);
+            int32_t j1 = min((ymax + pad - kSub / 2) >> kSubpixelBits, tile_y1);
+            if (r.flags & 1u) raster_wave<kAlpha, true, kSamples>(r, i0, i1, j0, j1, sink, fb, fc);
+            else raster_wave<kAlpha, false, kSamples>(r, i0, i1, j0, j1, sink, fb, fc);
         }
         __syncthreads();
     }
     if (!shared_tile) {
-        for (uint32_t k = tid; k < kTilePixels; k += 256u) dst[k] = s_vis[k];
+#pragma unroll
+        for (uint32_t smp = 0; smp < (uint32_t)kSamples; ++smp)
+            for (uint32_t k = tid; k < kTilePixels; k += 256u) dst[(size_t)smp * fb.vis_stride + k] = s_vis[smp * kTilePixels + k];
     } else {
-        for (uint32_t k = tid; k < kTilePixels; k += 256u) {
-            const unsigned long long v = s_vis[k];
-            if (v != kClearKey) __hip_atomic_fetch_min(&dst[k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+#pragma unroll
+        for (uint32_t smp = 0; smp < (uint32_t)kSamples; ++smp)
+            for (uint32_t k = tid; k < kTilePixels; k += 256u) {
+                const unsigned long long v = s_vis[smp * kTilePixels + k];
+                if (v != kClearKey) __hip_atomic_fetch_min(&dst[(size_t)smp * fb.vis_stride + k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
     }
 }
 
@@ -1612,7 +1699,8 @@ __device__ __forceinline__ void add_light_pair(const GpuLight& L, PixelPair& p, 
 template <int PPT, bool kShadows, int kSamples>
 __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(FrameBuffers fb) {
     FrameConstRef fc = frame_const_ref(fb.frame_const);
-    static_assert(kSamples == 1 || PPT == 1, "the MSAA variant shades one pixel per lane");
+    static_assert(kSamples == 1 || PPT == 2, "the MSAA variant shades one pixel per lane, two of its samples at a time");
+    constexpr uint32_t kPix = kSamples > 1 ? 1u : (uint32_t)PPT;        // pixels per lane
     __shared__ GpuLight s_lights[kMaxLights];
     __shared__ uint32_t s_bases[kLdsItems + 1];
     __shared__ float s_lut[kShadows ? 512 : 1];     // texel decode table (see FetchSrgb8), full variant only
@@ -1628,7 +1716,7 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(
         for (uint32_t k = tid; k < n_words; k += 256u) dst[k] = src[k];
     }
     const TileRef ref = fb.launch_order[blockIdx.x % fb.n_owned];
-    const uint32_t part = (blockIdx.x / fb.n_owned) * (256u * PPT);     // first tile-local pixel of this workgroup
+    const uint32_t part = (blockIdx.x / fb.n_owned) * (256u * kPix);    // first tile-local pixel of this workgroup
     const uint32_t tile_x0 = (ref.tile % fc.tiles_x) * kTile, tile_y0 = (ref.tile / fc.tiles_x) * kTile;
     const unsigned long long* vis0 = reinterpret_cast<const unsigned long long*>(fb.vis) + (size_t)ref.tile * kTilePixels;
     // A frame whose geometry phase overflowed an internal stream (records, clip queue, bin entries: triangles were
@@ -1655,27 +1743,31 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(
     unsigned long long key[PPT];
     bool covered[PPT];
     float sum_r = 0.0f, sum_g = 0.0f, sum_b = 0.0f;     // MSAA: running sum of the samples' f16 colours
-    uint32_t prev_id = RND_NONE;
+    uint32_t prev_id[PPT];
+    bool reuse[PPT];
+#pragma unroll
+    for (uint32_t k = 0; k < PPT; ++k) { prev_id[k] = RND_NONE; reuse[k] = false; }
     unsigned long long key0 = 0;
-  for (int smp = 0; smp < kSamples; ++smp) {
-    const unsigned long long* vis = vis0 + (size_t)smp * fb.vis_stride;
+  // MSAA: the lane's two "pixels" are two samples of ONE pixel (samples 0, 1, then 2, 3), so that the light loop runs
+  // on the packed pair path as it does for two pixels
+  for (int smp = 0; smp < kSamples; smp += (kSamples > 1 ? PPT : 1)) {
     // phase A: fragment inputs of this lane's pixels
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-    bool reuse = false;
 #pragma unroll
     for (uint32_t k = 0; k < PPT; ++k) {
-        uint32_t local = part + wave * (64u * PPT) + k * 64u + lane;      // a wave holds 2*PPT consecutive rows
+        const unsigned long long* vis = vis0 + (size_t)(kSamples > 1 ? (uint32_t)smp + k : 0u) * fb.vis_stride;
+        uint32_t local = part + wave * (64u * kPix) + (kSamples > 1 ? 0u : k * 64u) + lane;      // a wave holds 2*kPix consecutive rows
         uint32_t i = tile_x0 + (local & (kTile - 1)), j = tile_y0 + (local / kTile);
         key[k] = vis[local];
         uint32_t id = (uint32_t)(key[k] & 0xFFFFFFFFull);
         if constexpr (kSamples > 1) {
-            if (smp == 0) key0 = key[k];
-            // same triangle as the previous sample: same fragment, same colour (px[k] still holds it)
-            reuse = smp > 0 && id == prev_id;
-            prev_id = id;
+            if (smp == 0 && k == 0) key0 = key[k];
+            // same triangle as two samples ago: same fragment (shaded at the pixel centre), same colour: px[k] still holds it
+            reuse[k] = smp > 0 && id == prev_id[k];
+            prev_id[k] = id;
         }
         covered[k] = i < fc.width && j < fc.height && id != RND_NONE;
-        if constexpr (kSamples > 1) covered[k] = covered[k] && !reuse;
+        if constexpr (kSamples > 1) covered[k] = covered[k] && !reuse[k];
         if (covered[k] && !guard(id < fc.n_tris, fb.counters, kGuardShade)) covered[k] = false;
         // the fragment's inputs go to `fresh`, left unset on lanes without a fragment; the defaults are
         // selected once, after the item paths have merged (initializing up front made every merge point
@@ -1704,7 +1796,7 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(
                 }
             }
         }
-        if (kSamples == 1 || !reuse) {
+        if (kSamples == 1 || !reuse[k]) {
             if (covered[k]) px[k] = fresh;
             else {
                 px[k] = PixelInputs{};
@@ -1735,7 +1827,7 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(
         RND_PAIR(fx); RND_PAIR(fy); RND_PAIR(fz); RND_PAIR(Nx); RND_PAIR(Ny); RND_PAIR(Nz); RND_PAIR(Vx); RND_PAIR(Vy);
         RND_PAIR(Vz); RND_PAIR(br); RND_PAIR(bg); RND_PAIR(bb); RND_PAIR(cr); RND_PAIR(cg); RND_PAIR(cb);
 #undef RND_PAIR
-        pp.lit0 = px[0].lit; pp.lit1 = px[1].lit;
+        pp.lit0 = px[0].lit && (kSamples == 1 || covered[0]); pp.lit1 = px[1].lit && (kSamples == 1 || covered[1]);
         pp.ar = pp.ag = pp.ab = splat2(0.0f);
     }
 #endif
@@ -1790,12 +1882,16 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(
 #if RND_FAST_SHADE
     if constexpr (PPT == 2) {
         pp.cr += pp.br * pp.ar; pp.cg += pp.bg * pp.ag; pp.cb += pp.bb * pp.ab;
+        // (a re-used sample keeps the colour it was shaded to; its lit flag was off, so the sum above left it as it was)
         px[0].cr = pp.cr.x; px[0].cg = pp.cg.x; px[0].cb = pp.cb.x;
         px[1].cr = pp.cr.y; px[1].cg = pp.cg.y; px[1].cb = pp.cb.y;
     }
 #endif
     if constexpr (kSamples > 1) {
-        sum_r = sum_r + round_f16(px[0].cr); sum_g = sum_g + round_f16(px[0].cg); sum_b = sum_b + round_f16(px[0].cb);
+#pragma unroll
+        for (uint32_t k = 0; k < PPT; ++k) {
+            sum_r = sum_r + round_f16(px[k].cr); sum_g = sum_g + round_f16(px[k].cg); sum_b = sum_b + round_f16(px[k].cb);
+        }
     }
   }
     if constexpr (kSamples > 1) {
@@ -1804,8 +1900,8 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(
     }
     // phase D: f16 target, tone map, sRGB (show_texture.wgsl + the sRGB surface)
 #pragma unroll
-    for (uint32_t k = 0; k < PPT; ++k) {
-        uint32_t local = part + wave * (64u * PPT) + k * 64u + lane;
+    for (uint32_t k = 0; k < kPix; ++k) {
+        uint32_t local = part + wave * (64u * kPix) + k * 64u + lane;
         uint32_t i = tile_x0 + (local & (kTile - 1)), j = tile_y0 + (local / kTile);
         bool inside = i < fc.width && j < fc.height;
         float hr = round_f16(px[k].cr), hg = round_f16(px[k].cg), hb = round_f16(px[k].cb);
@@ -2080,7 +2176,7 @@ void launch_clear(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stre
     const uint32_t n_vec = (uint32_t)(table_bytes / 16);
     // enough workgroups for the table copy even when this context owns few tiles
     const uint32_t blocks = std::max<uint32_t>(fb.n_owned ? fb.n_owned : 1u, std::min<uint32_t>(div_up(n_vec, 256), 1024u));
-    hipLaunchKernelGGL(k_clear, dim3(blocks), dim3(256), 0, stream, fb, n_counts, n_vblocks,
+    hipLaunchKernelGGL(k_clear, dim3(blocks), dim3(256), 0, stream, fb, n_counts, n_vblocks, std::max(fc.n_samples, 1u),
                        static_cast<const uint4*>(host_tables), static_cast<uint4*>(dev_tables), n_vec);
 }
 
@@ -2095,8 +2191,14 @@ void launch_transform(const FrameBuffers& fb, const FrameConst& fc, hipStream_t 
 }
 void launch_setup(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {
     if (!fc.n_tris) return;
-    if (fb.alpha_test) hipLaunchKernelGGL(k_setup<true>, dim3(fc.n_units), dim3(256), 0, stream, fb, cap);
-    else hipLaunchKernelGGL(k_setup<false>, dim3(fc.n_units), dim3(256), 0, stream, fb, cap);
+    const bool ms = fc.n_samples == 4u;
+    if (fb.alpha_test) {
+        if (ms) hipLaunchKernelGGL((k_setup<true, 4>), dim3(fc.n_units), dim3(256), 0, stream, fb, cap);
+        else hipLaunchKernelGGL((k_setup<true, 1>), dim3(fc.n_units), dim3(256), 0, stream, fb, cap);
+    } else {
+        if (ms) hipLaunchKernelGGL((k_setup<false, 4>), dim3(fc.n_units), dim3(256), 0, stream, fb, cap);
+        else hipLaunchKernelGGL((k_setup<false, 1>), dim3(fc.n_units), dim3(256), 0, stream, fb, cap);
+    }
 }
 void launch_clip(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {
     if (!fc.n_tris) return;
@@ -2113,16 +2215,23 @@ void launch_bin(const FrameBuffers& fb, const FrameConst& fc, const Capacities& 
 }
 void launch_raster(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {
     if (!fb.n_owned) return;
-    if (fb.alpha_test) hipLaunchKernelGGL(k_raster<true>, dim3(fb.n_owned + kRasterExtraCap), dim3(256), 0, stream, fb, cap);
-    else hipLaunchKernelGGL(k_raster<false>, dim3(fb.n_owned + kRasterExtraCap), dim3(256), 0, stream, fb, cap);
+    const bool ms = fc.n_samples == 4u;
+    const dim3 grid(fb.n_owned + kRasterExtraCap);
+    if (fb.alpha_test) {
+        if (ms) hipLaunchKernelGGL((k_raster<true, 4>), grid, dim3(256), 0, stream, fb, cap);
+        else hipLaunchKernelGGL((k_raster<true, 1>), grid, dim3(256), 0, stream, fb, cap);
+    } else {
+        if (ms) hipLaunchKernelGGL((k_raster<false, 4>), grid, dim3(256), 0, stream, fb, cap);
+        else hipLaunchKernelGGL((k_raster<false, 1>), grid, dim3(256), 0, stream, fb, cap);
+    }
 }
 void launch_shade(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream) {
     if (!fb.n_owned) return;
     static const int ppt = [] { const char* e = getenv("RND_SHADE_PPT"); int v = e ? atoi(e) : 2; return (v == 1 || v == 2 || v == 4) ? v : 1; }();
     const bool sh = fb.shadow_sets != nullptr || fb.has_textures;
     if (fc.n_samples == 4) {
-        if (sh) hipLaunchKernelGGL((k_shade<1, true, 4>), dim3(fb.n_owned * 4), dim3(256), 0, stream, fb);
-        else hipLaunchKernelGGL((k_shade<1, false, 4>), dim3(fb.n_owned * 4), dim3(256), 0, stream, fb);
+        if (sh) hipLaunchKernelGGL((k_shade<2, true, 4>), dim3(fb.n_owned * 4), dim3(256), 0, stream, fb);
+        else hipLaunchKernelGGL((k_shade<2, false, 4>), dim3(fb.n_owned * 4), dim3(256), 0, stream, fb);
     } else if (ppt == 4) {
         if (sh) hipLaunchKernelGGL((k_shade<4, true, 1>), dim3(fb.n_owned), dim3(256), 0, stream, fb);
         else hipLaunchKernelGGL((k_shade<4, false, 1>), dim3(fb.n_owned), dim3(256), 0, stream, fb);

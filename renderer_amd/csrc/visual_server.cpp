@@ -607,8 +607,7 @@ void VisualServer::build_frame(std::vector<DrawItem>& items, std::vector<uint32_
     fc.ndc_step_xf = (float)fc.ndc_step_x; fc.ndc_step_yf = (float)fc.ndc_step_y;
     fc.n_samples = msaa_;
     fc.n_views = 1; fc.view_h = height_; fc.view_mask = 1u; fc.n_units_view = fc.n_units;      // (multi-view: the shadow passes only)
-    fc.sub_dx = fc.sub_dy = 0;
-    if (msaa_ > 1) sample_shift(0, fc.sub_dx, fc.sub_dy);
+    fc.sub_dx = fc.sub_dy = 0;        // (MSAA: the four sample positions are evaluated per pixel in ONE geometry pass)
 }
 
 // Whether any shadow-casting instance can reach a cascade's clip volume: the bounds of each submesh
@@ -658,14 +657,6 @@ bool VisualServer::cascade_has_casters(const Mat4& cascade) const {
 }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
-// The standard 4x sample pattern, offsets from the pixel corner in 1/16 px; the shift that puts sample
-// `smp` on the pixel centre, in sub-pixel steps.
-void VisualServer::sample_shift(uint32_t smp, int32_t& dx, int32_t& dy) {
-    static const int32_t k16[4][2] = {{6, 2}, {14, 6}, {2, 10}, {10, 14}};
-    dx = kSub / 2 - k16[smp & 3][0] * (kSub / 16);
-    dy = kSub / 2 - k16[smp & 3][1] * (kSub / 16);
-}
 
 // A bump allocator over the static scratch array: sizes are added up first (nothing is dereferenced), the
 // frame is rejected before any launch when the sum exceeds the array.
@@ -738,7 +729,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         d_tile_count_.ensure(2 * need); d_tile_offset_.ensure(need); d_tile_cursor_.ensure(need);
     }
     // (members that describe "the last enqueued frame" change only after the last point where this one can be rejected)
-    const uint32_t n_counter_sets = 1 + n_passes + (msaa_ - 1);
+    const uint32_t n_counter_sets = 1 + n_passes;
     if (!noalloc) d_counters_[p].ensure(n_counter_sets);
     if (h_counter_sets_ < n_counter_sets) {
         if (frame_pending_) HIP_CHECK(hipStreamSynchronize(stream_));
@@ -816,10 +807,9 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     const size_t off_li = align_up(off_ub + unit_bases.size() * 4, 256);
     const size_t off_si = align_up(off_li + lights.size() * sizeof(GpuLight), 256);
     const size_t off_ss = align_up(off_si + (n_sets ? shadow_items.size() * sizeof(DrawItem) : 0), 256);
-    // the constants of every pass of the frame: [0] main pass (sample 0), then one per shadow pass,
-    // then one per further MSAA sample
+    // the constants of every pass of the frame: [0] main pass, then one per shadowed light
     std::vector<FrameConst>& consts = consts_;
-    consts.assign(1 + n_passes + (msaa_ - 1), fc);
+    consts.assign(1 + n_passes, fc);
     // Which cascades of which light are drawn / cleared this frame.  A cascade no caster can reach stays cleared: it
     // is left out of the pass (view_mask), and its layer is only cleared again if it was drawn into since.
     std::vector<uint32_t> draw_mask(n_sets, 0u), clear_mask(n_sets, 0u);
@@ -840,7 +830,6 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         sfc.rank = 0; sfc.world = 1; sfc.n_lights = 0;
         sfc.n_samples = 1; sfc.sub_dx = sfc.sub_dy = 0;      // shadow maps are single-sampled (visual_server.rs:371)
     }
-    for (uint32_t smp = 1; smp < msaa_; ++smp) sample_shift(smp, consts[n_passes + smp].sub_dx, consts[n_passes + smp].sub_dy);
     constexpr size_t kConstSlot = (sizeof(FrameConst) + 255) / 256 * 256;
     const size_t off_fc = align_up(off_ss + n_sets * sizeof(ShadowSet), 256);
     // the 2D pass's quads, when anything 2D is set
@@ -1029,23 +1018,6 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     launch_bin(fb, fc, cap_, gs);
     mark(4, gs);
     launch_raster(fb, fc, cap_, gs);
-    // MSAA: the other samples' visibility planes, one more geometry pass each with the snapped
-    // vertices moved so that the sample sits on the pixel centre (clip positions are shared)
-    for (uint32_t smp = 1; smp < msaa_; ++smp) {
-        FrameBuffers mfb = fb;
-        mfb.vis = bp.vis + (size_t)smp * fb.vis_stride;
-        mfb.counters = bp.counters + 1 + n_passes + (smp - 1);
-        counter_set_ran_[1 + n_passes + (smp - 1)] = 1;
-        const FrameConst& mfc = consts[n_passes + smp];
-        mfb.frame_const = const_slot(n_passes + smp);
-        clear(mfb, mfc);
-        launch_cull(mfb, mfc, gs);
-        launch_setup(mfb, mfc, cap_, gs);
-        launch_clip(mfb, mfc, cap_, gs);
-        launch_scan(mfb, mfc, cap_, gs);
-        launch_bin(mfb, mfc, cap_, gs);
-        launch_raster(mfb, mfc, cap_, gs);
-    }
     mark(5, gs);
     if (overlap_) HIP_CHECK(hipEventRecord(geo_done_[p], gs));
     if (overlap) HIP_CHECK(hipStreamWaitEvent(stream_, geo_done_[p], 0));

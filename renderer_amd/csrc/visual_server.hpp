@@ -174,7 +174,6 @@ private:
     uint32_t surface_w_ = 0, surface_h_ = 0;
     bool frame_alpha_test_ = false, frame_textured_ = false;      // set by build_frame
     void apply_size(uint32_t sw, uint32_t sh, float factor);
-    static void sample_shift(uint32_t smp, int32_t& dx, int32_t& dy);
     bool scaled() const { return width_ != surface_w_ || height_ != surface_h_; }
     DeviceBuffer<uint8_t> d_present_;     // surface-sized RGBA8 when scaled()
     float render_size_factor_ = 1.0f;
