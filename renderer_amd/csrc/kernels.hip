@@ -1636,6 +1636,7 @@ __device__ __forceinline__ void add_light(const GpuLight& L, PixelInputs& p, con
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct PixelPair {
     f32x2 fx, fy, fz, Nx, Ny, Nz, Vx, Vy, Vz, br, bg, bb, cr, cg, cb;
+    f32x2 NV;               // N . V
     f32x2 ar, ag, ab;       // sum over the lights of colour * intensity * (diffuse + specular)
     bool lit0, lit1;
 };
@@ -1648,44 +1649,61 @@ __device__ __forceinline__ float shadow_term(const ShadowSet* __restrict__ sets,
     return light_occlusion(sets, L.shadow_index, fc, fx, fy, fz, nx, ny, nz, L.dir[0], L.dir[1], L.dir[2]);
 }
 
+// The lane's lit flags are not looked at here (except to skip shadow look-ups): a lane without a lit fragment
+// computes on zeros and the caller drops its sum.  Straight-line for a point light: beyond the radius the clamped
+// linear term is zero and so is the light's weight, which is what the reference's discard amounts to.
+//   o = frag - light (unnormalized), dist = |o|:   diffuse = max(-(N.o) / dist, 0)
+//   half vector scaled by dist: h' = V * dist - o;  specular base = max((N.h') / |h'|, 0), with N.h' = (N.V) dist - N.o
+// (five packed operations less than normalizing o first; N.V is per fragment, outside the light loop)
 template <bool kShadows>
 __device__ __forceinline__ void add_light_pair(const GpuLight& L, PixelPair& p, const ShadowSet* __restrict__ sets,
                                                FrameConstRef fc) {
 #pragma clang fp contract(fast)
-    f32x2 dx, dy, dz, inten;
+    f32x2 ox, oy, oz, inv_d, dist, inten;
     if (L.kind == RND_LIGHT_DIRECTIONAL) {
-        dx = splat2(L.dir[0]); dy = splat2(L.dir[1]); dz = splat2(L.dir[2]);
-        float i0 = p.lit0 ? L.color[3] : 0.0f, i1 = p.lit1 ? L.color[3] : 0.0f;
+        ox = splat2(L.dir[0]); oy = splat2(L.dir[1]); oz = splat2(L.dir[2]);
+        inv_d = dist = splat2(1.0f);
+        float i0 = L.color[3], i1 = L.color[3];
         if constexpr (kShadows) {
             if (p.lit0) i0 = L.color[3] * (1.0f - shadow_term(sets, L, fc, p.fx.x, p.fy.x, p.fz.x, p.Nx.x, p.Ny.x, p.Nz.x));
             if (p.lit1) i1 = L.color[3] * (1.0f - shadow_term(sets, L, fc, p.fx.y, p.fy.y, p.fz.y, p.Nx.y, p.Ny.y, p.Nz.y));
         }
         inten = (f32x2){i0, i1};
     } else {
-        f32x2 ox = p.fx - splat2(L.pos[0]), oy = p.fy - splat2(L.pos[1]), oz = p.fz - splat2(L.pos[2]);
+        ox = p.fx - splat2(L.pos[0]); oy = p.fy - splat2(L.pos[1]); oz = p.fz - splat2(L.pos[2]);
         f32x2 d2 = ox * ox + oy * oy + oz * oz;
-        f32x2 inv_d = rsq2(d2);
-        f32x2 dist = d2 * inv_d;
-        const bool in0 = p.lit0 && dist.x <= L.radius, in1 = p.lit1 && dist.y <= L.radius;
-        if (!in0 && !in1) return;
-        f32x2 lin = (splat2(L.radius) - dist) * splat2(L.inv_radius);
+        inv_d = rsq2(d2);
+        dist = d2 * inv_d;
+        f32x2 lin = splat2(1.0f) - dist * splat2(L.inv_radius);
         lin = (f32x2){fminf(fmaxf(lin.x, 0.0f), 1.0f), fminf(fmaxf(lin.y, 0.0f), 1.0f)};
-        f32x2 att = (lin * lin) * (splat2(3.0f) - splat2(2.0f) * lin);
-        inten = splat2(L.color[3]) * att;
-        inten = (f32x2){in0 ? inten.x : 0.0f, in1 ? inten.y : 0.0f};
-        dx = ox * inv_d; dy = oy * inv_d; dz = oz * inv_d;
+        inten = ((lin * lin) * (splat2(3.0f) - splat2(2.0f) * lin)) * splat2(L.color[3]);
     }
-    f32x2 diff = max0(-(p.Nx * dx + p.Ny * dy + p.Nz * dz));
-    f32x2 hx = p.Vx - dx, hy = p.Vy - dy, hz = p.Vz - dz;
+    f32x2 No = p.Nx * ox + p.Ny * oy + p.Nz * oz;
+    f32x2 diff = max0(-(No * inv_d));
+    f32x2 hx = p.Vx * dist - ox, hy = p.Vy * dist - oy, hz = p.Vz * dist - oz;
     f32x2 inv_h = rsq2(hx * hx + hy * hy + hz * hz);
-    f32x2 sp = max0((p.Nx * hx + p.Ny * hy + p.Nz * hz) * inv_h);
-    f32x2 s2 = sp * sp, s4 = s2 * s2, s8 = s4 * s4;
+    f32x2 sp = max0((p.NV * dist - No) * inv_h);
+    f32x2 s2 = sp * sp, s4 = s2 * s2;
     // the lights' sum is kept apart from the base colour and multiplied in once after the loop
     // (base * sum(c_l * w_l) for sum(base * c_l * w_l): three packed multiplies less per light)
-    f32x2 w = (diff + s8) * inten;
+    f32x2 w = (s4 * s4 + diff) * inten;
     p.ar += splat2(L.color[0]) * w;
     p.ag += splat2(L.color[1]) * w;
     p.ab += splat2(L.color[2]) * w;
+}
+
+// one light through scalar loads (its index is wave-uniform)
+__device__ __forceinline__ GpuLight load_light_uniform(const GpuLight* lights, uint32_t li) {
+    typedef const __attribute__((address_space(4))) GpuLight* cptr_light;
+    cptr_light lp = (cptr_light)lights + li;
+    GpuLight L;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { L.pos[c] = lp->pos[c]; L.dir[c] = lp->dir[c]; }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) L.color[c] = lp->color[c];
+    L.radius = lp->radius; L.kind = lp->kind; L.shadow_index = lp->shadow_index; L.inv_radius = lp->inv_radius;
+    L.pad[0] = L.pad[1] = 0;
+    return L;
 }
 #endif
 
@@ -1829,6 +1847,7 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(
 #undef RND_PAIR
         pp.lit0 = px[0].lit && (kSamples == 1 || covered[0]); pp.lit1 = px[1].lit && (kSamples == 1 || covered[1]);
         pp.ar = pp.ag = pp.ab = splat2(0.0f);
+        pp.NV = pp.Nx * pp.Vx + pp.Ny * pp.Vy + pp.Nz * pp.Vz;
     }
 #endif
     if (lo[0] <= hi[0]) {
@@ -1848,6 +1867,26 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(
                     keep = dd <= rr * rr;
                 }
             }
+#if RND_FAST_SHADE && RND_SCALAR_LIGHTS
+            if constexpr (PPT == 2) {
+                // the next surviving light's 64 bytes are requested (scalar loads) before the current one is worked on
+                unsigned long long km = __ballot(keep);
+                if (km == 0ull) continue;
+                GpuLight cur = load_light_uniform(fb.lights, __builtin_amdgcn_readfirstlane(group + (uint32_t)(__ffsll((long long)km) - 1)));
+                km &= km - 1ull;
+                for (;;) {
+                    const bool more = km != 0ull;
+                    // (the last light is loaded a second time rather than branching around the load)
+                    const uint32_t ni = more ? group + (uint32_t)(__ffsll((long long)km) - 1) : 0u;
+                    const GpuLight nxt = load_light_uniform(fb.lights, __builtin_amdgcn_readfirstlane(ni));
+                    add_light_pair<kShadows>(cur, pp, fb.shadow_sets, fc);
+                    if (!more) break;
+                    km &= km - 1ull;
+                    cur = nxt;
+                }
+                continue;
+            }
+#endif
             for (unsigned long long km = __ballot(keep); km; km &= km - 1ull) {
                 // the whole light at once (16 B LDS reads, one wait) rather than field by field as the
                 // branches below get to them
@@ -1882,9 +1921,9 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(
 #if RND_FAST_SHADE
     if constexpr (PPT == 2) {
         pp.cr += pp.br * pp.ar; pp.cg += pp.bg * pp.ag; pp.cb += pp.bb * pp.ab;
-        // (a re-used sample keeps the colour it was shaded to; its lit flag was off, so the sum above left it as it was)
-        px[0].cr = pp.cr.x; px[0].cg = pp.cg.x; px[0].cb = pp.cb.x;
-        px[1].cr = pp.cr.y; px[1].cg = pp.cg.y; px[1].cb = pp.cb.y;
+        // (a lane without a lit fragment keeps its colour; so does a re-used sample: the one it was shaded to)
+        if (pp.lit0) { px[0].cr = pp.cr.x; px[0].cg = pp.cg.x; px[0].cb = pp.cb.x; }
+        if (pp.lit1) { px[1].cr = pp.cr.y; px[1].cg = pp.cg.y; px[1].cb = pp.cb.y; }
     }
 #endif
     if constexpr (kSamples > 1) {
