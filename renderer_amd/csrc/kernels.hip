@@ -657,19 +657,21 @@ __device__ __forceinline__ uint32_t count_wave(bool emit, const TileRect& t, uin
 
 // Reject / cull / record of one triangle from its three pre-snapped vertices (K1 did the per-vertex
 // work: snap_and_classify); sets need_clip (and emits nothing) when it must go through the clipper.
-__device__ __forceinline__ void setup_triangle(const SnapVert& v0, const SnapVert& v1, const SnapVert& v2, uint32_t gid,
+__device__ __forceinline__ void setup_triangle(bool live, const SnapVert& v0, const SnapVert& v1, const SnapVert& v2, uint32_t gid,
                                                FrameConstRef fc, int32_t j_lo, int32_t j_hi, SetupRecord& rec, TileRect& tr, bool& emit,
                                                bool& need_clip) {
     const uint32_t any = v0.code | v1.code | v2.code, all = v0.code & v1.code & v2.code;
     // dropped: a non-finite coordinate, or all three vertices outside one plane of the view volume
-    const bool go = !(any & kOutNonFinite) && !(all & kOutPlanes);
+    const bool go = live && !(any & kOutNonFinite) && !(all & kOutPlanes);
     need_clip = go && (any & kOutNeedsClip) != 0u;
-    if (go && !need_clip) {
-        const Snapped s0{v0.x + fc.sub_dx, v0.y + fc.sub_dy, v0.z}, s1{v1.x + fc.sub_dx, v1.y + fc.sub_dy, v1.z},
-                      s2{v2.x + fc.sub_dx, v2.y + fc.sub_dy, v2.z};
-        const bool rec_ok = make_record(s0, s1, s2, gid, fc, j_lo, j_hi, rec, tr);
-        emit = !(any & kOutBehind) && rec_ok && any_owned(tr, fc);
-    }
+    // straight-line: the record is made for every lane (integers and one reciprocal: garbage in, defined garbage out)
+    // and the verdict is a predicate; a branch around it made every field of rec and tr a merge of "computed" and
+    // "zero" (some forty moves per 64 triangles)
+    const Snapped s0{v0.x + fc.sub_dx, v0.y + fc.sub_dy, v0.z}, s1{v1.x + fc.sub_dx, v1.y + fc.sub_dy, v1.z},
+                  s2{v2.x + fc.sub_dx, v2.y + fc.sub_dy, v2.z};
+    const bool rec_ok = make_record(s0, s1, s2, gid, fc, j_lo, j_hi, rec, tr);
+    emit = go && !need_clip && !(any & kOutBehind) && rec_ok;
+    if (fc.world > 1u) emit = emit && any_owned(tr, fc);
 }
 
 // Direct raster, wave-cooperative.  Per wave only a quarter of the triangles survive culling, and a
@@ -794,29 +796,35 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
     const uint32_t n_tiles = fc.tiles_x * fc.tiles_y;
     const GlobalSink direct_sink{reinterpret_cast<unsigned long long*>(fb.vis), fc.tiles_x, fc.rank, fc.world, fb.vis_stride};
     uint32_t valid = 0;
-    for (uint32_t iter = 0; iter < chunk_tris / 256u; ++iter) {
+    // (a unit without triangles or with tables that do not fit runs no iteration; the loads below need nv >= 1)
+    const uint32_t n_iters = (tables_ok && nv != 0u) ? (n_here + 255u) / 256u : 0u;
+    for (uint32_t iter = 0; iter < n_iters; ++iter) {
         const uint32_t local = iter * 256u + threadIdx.x;
         const uint32_t gid = tri_base + first_t + local;                   // draw-order triangle id
         bool emit = false, need_clip = false;
         SetupRecord rec;
-        TileRect tr{0, 0, 0, 0, 0, 0, 0, 0};
-        if (local < n_here && tables_ok) {
-            gptr_u32 ix = indices + 3ull * (first_t + local);
-            const uint32_t i0 = ix[0], i1 = ix[1], i2 = ix[2];
-            if (guard(i0 < nv && i1 < nv && i2 < nv, fb.counters, kGuardSetup)) {
-                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                u32x4 q0 = *reinterpret_cast<const u32x4*>(snap_v + vb + i0);
-                u32x4 q1 = *reinterpret_cast<const u32x4*>(snap_v + vb + i1);
-                u32x4 q2 = *reinterpret_cast<const u32x4*>(snap_v + vb + i2);
-                // three whole 16-byte gathers in one round trip: left alone the compiler loads the outcodes
-                // first and sinks the positions into the branch that uses them (six gathers, two round trips)
-                asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2));
-                const SnapVert v0{(int32_t)q0.x, (int32_t)q0.y, __uint_as_float(q0.z), q0.w};
-                const SnapVert v1{(int32_t)q1.x, (int32_t)q1.y, __uint_as_float(q1.z), q1.w};
-                const SnapVert v2{(int32_t)q2.x, (int32_t)q2.y, __uint_as_float(q2.z), q2.w};
-                setup_triangle(v0, v1, v2, gid, fc, j_lo, j_hi, rec, tr, emit, need_clip);
-                if (alpha_item) rec.flags |= 2u;
-            }
+        TileRect tr;
+        {
+            // straight-line: a lane beyond the chunk's end works on the chunk's first triangle, an index beyond the
+            // item's vertices is clamped and reported; both are dropped by the predicate
+            const bool in = local < n_here;
+            gptr_u32 ix = indices + 3ull * (first_t + (in ? local : 0u));
+            uint32_t i0 = ix[0], i1 = ix[1], i2 = ix[2];
+            const bool idx_ok = max(i0, max(i1, i2)) < nv;
+            guard(idx_ok, fb.counters, kGuardSetup);
+            i0 = min(i0, nv - 1u); i1 = min(i1, nv - 1u); i2 = min(i2, nv - 1u);
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 q0 = *reinterpret_cast<const u32x4*>(snap_v + vb + i0);
+            u32x4 q1 = *reinterpret_cast<const u32x4*>(snap_v + vb + i1);
+            u32x4 q2 = *reinterpret_cast<const u32x4*>(snap_v + vb + i2);
+            // three whole 16-byte gathers in one round trip: left alone the compiler loads the outcodes
+            // first and sinks the positions into the branch that uses them (six gathers, two round trips)
+            asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2));
+            const SnapVert v0{(int32_t)q0.x, (int32_t)q0.y, __uint_as_float(q0.z), q0.w};
+            const SnapVert v1{(int32_t)q1.x, (int32_t)q1.y, __uint_as_float(q1.z), q1.w};
+            const SnapVert v2{(int32_t)q2.x, (int32_t)q2.y, __uint_as_float(q2.z), q2.w};
+            setup_triangle(in && idx_ok, v0, v1, v2, gid, fc, j_lo, j_hi, rec, tr, emit, need_clip);
+            if (alpha_item) rec.flags |= 2u;
         }
         // queue the triangles that need the clipper (wave-compacted, rare)
         unsigned long long cm = __ballot(need_clip);
