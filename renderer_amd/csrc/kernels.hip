@@ -516,19 +516,22 @@ __device__ __forceinline__ void pixel_samples(W w0, W w1, W w2, W b0, W b1, W b2
 struct GlobalSink {
     unsigned long long* vis;
     uint32_t tiles_x, rank, world;
-    uint64_t plane_stride;              // words between the planes of consecutive MSAA samples
+    uint32_t plane_stride;              // words between the planes of consecutive MSAA samples
     __device__ __forceinline__ void operator()(int32_t i, int32_t j, float z, uint32_t id, uint32_t smp = 0) const {
         z = fminf(fmaxf(z, 0.0f), 1.0f);
         const uint32_t tx = (uint32_t)i / kTile, ty = (uint32_t)j / kTile;
         if (z < 1.0f && owns_tile(tx, ty, rank, world)) {
             unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | id;
-            const size_t at = (size_t)smp * plane_stride + (size_t)(ty * tiles_x + tx) * kTilePixels + (((uint32_t)j % kTile) * kTile + ((uint32_t)i % kTile));
+            // a 32-bit byte offset from the (uniform) base: the largest target, 8192 x 8192 x 4 samples, is 2^31 bytes
+            // (kMaxRenderSize), and the address is then one scalar base + one vector offset
+            const uint32_t at = smp * plane_stride + (ty * tiles_x + tx) * kTilePixels + (((uint32_t)j % kTile) * kTile + ((uint32_t)i % kTile));
+            unsigned long long* const word = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(vis) + (at << 3));
 #if RND_EARLY_Z
             // early test with a plain (possibly stale) load: the word only ever decreases, so a stale
             // value can cause a redundant atomic, never a skipped one
-            if (!(key < vis[at])) return;
+            if (!(key < *word)) return;
 #endif
-            __hip_atomic_fetch_min(&vis[at], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_min(word, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 };
@@ -728,7 +731,8 @@ __device__ __forceinline__ DirectTri make_direct(const SetupRecord& r, const Til
 }
 
 // pixel k (row-major in the bbox) of a compacted triangle
-template <bool kAlpha, int kSamples, class Sink>
+// kTriPlane: the triangle entry names the one sample plane it resolves (k_setup's MSAA rounds)
+template <bool kAlpha, int kSamples, bool kTriPlane, class Sink>
 __device__ __forceinline__ void direct_pixel(const DirectTri& d, uint32_t k, const Sink& sink, const FrameBuffers& fb,
                                              FrameConstRef fc) {
     const uint32_t w = d.shape & 255u;
@@ -750,7 +754,7 @@ __device__ __forceinline__ void direct_pixel(const DirectTri& d, uint32_t k, con
         [&](int32_t s1, int32_t s2, uint32_t smp) {
             const float l1 = (float)s1 * d.inv_area, l2 = (float)s2 * d.inv_area;
             const float z = (l1 * d.dz1 + l2 * d.dz2) + d.z0;
-            sink((int32_t)i, (int32_t)j, z, d.id, kSamples == 1 ? d.smp : smp);
+            sink((int32_t)i, (int32_t)j, z, d.id, kTriPlane ? d.smp : smp);
         });
 }
 
@@ -794,7 +798,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
     const bool tables_ok = guard(vb + nv <= fc.n_verts, fb.counters, kGuardSetup);
     const uint32_t chunk_base = blockIdx.x * chunk_tris;
     const uint32_t n_tiles = fc.tiles_x * fc.tiles_y;
-    const GlobalSink direct_sink{reinterpret_cast<unsigned long long*>(fb.vis), fc.tiles_x, fc.rank, fc.world, fb.vis_stride};
+    const GlobalSink direct_sink{reinterpret_cast<unsigned long long*>(fb.vis), fc.tiles_x, fc.rank, fc.world, (uint32_t)fb.vis_stride};
     uint32_t valid = 0;
     // (a unit without triangles or with tables that do not fit runs no iteration; the loads below need nv >= 1)
     const uint32_t n_iters = (tables_ok && nv != 0u) ? (n_here + 255u) / 256u : 0u;
@@ -866,7 +870,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
                     const uint4* src = s_direct[wave][which];
                     dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3]; dst[4] = src[4];
                     const uint32_t npix = (dt.shape >> 8) & 255u;
-                    for (uint32_t k = lane & 3u; k < npix; k += 4u) direct_pixel<kAlpha, 1>(dt, k, direct_sink, fb, fc);
+                    for (uint32_t k = lane & 3u; k < npix; k += 4u) direct_pixel<kAlpha, 1, (kSamples > 1)>(dt, k, direct_sink, fb, fc);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1317,7 +1321,7 @@ __global__ __launch_bounds__(256) void k_raster(FrameBuffers fb, Capacities cap)
             tr.j1 = min((ymax + pad - kSub / 2) >> kSubpixelBits, tile_y1);
             const DirectTri dt = make_direct(r, tr);
             const uint32_t npix = (dt.shape >> 8) & 255u;
-            for (uint32_t k = tid % kMediumLanes; k < npix; k += kMediumLanes) direct_pixel<kAlpha, kSamples>(dt, k, sink, fb, fc);
+            for (uint32_t k = tid % kMediumLanes; k < npix; k += kMediumLanes) direct_pixel<kAlpha, kSamples, false>(dt, k, sink, fb, fc);
         }
         for (uint32_t q = tid >> 6; q < nlarge; q += 4u) {
             SetupRecord r;
