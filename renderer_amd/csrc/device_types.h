@@ -18,6 +18,7 @@ constexpr int kSubpixelBits = 8;
 constexpr int kSub = 1 << kSubpixelBits;       // 256 sub-pixel steps per pixel
 constexpr float kGuardBand = 16.0f;            // guard band half-extent in NDC units
 constexpr uint32_t kMaxRenderSize = 8192;      // tile coordinates are packed in 8 bits
+constexpr uint32_t kXcds = 8;                   // MI355X: workgroup b of a launch runs on XCD b % 8, each XCD with its own L2
 constexpr uint64_t kClearKey = (uint64_t(0x3F800000u) << 32) | 0xFFFFFFFFull;   // depth 1.0, no triangle
 constexpr uint32_t kMaxLights = 256;
 constexpr uint32_t kChunkTris = 1024;          // triangles per setup work unit (one workgroup) in large frames

@@ -776,9 +776,15 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
     __shared__ uint32_t s_used;         // record slots of this workgroup's chunk handed out so far
     __shared__ uint32_t s_valid[4];
     __shared__ uint4 s_direct[4][64][5];   // per wave: the compacted small triangles of one iteration
-    if (blockIdx.x >= fb.counters->n_active) return;
+    // Workgroups go to the eight XCDs round-robin (workgroup b to XCD b % 8), and each XCD has its own L2.  Units
+    // next to each other in the list share vertices (the neighbouring rows of a mesh lie a few chunks apart), so
+    // every XCD takes one contiguous eighth of the list instead of every eighth unit.
+    const uint32_t n_active = fb.counters->n_active;
+    const uint32_t per_xcd = (n_active + kXcds - 1u) / kXcds;
+    const uint32_t unit_index = (blockIdx.x % kXcds) * per_xcd + blockIdx.x / kXcds;
+    if (blockIdx.x / kXcds >= per_xcd || unit_index >= n_active) return;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    const uint2 unit = fb.active_units[blockIdx.x];
+    const uint2 unit = fb.active_units[unit_index];
     const uint32_t item_s = __builtin_amdgcn_readfirstlane(unit.x), chunk_s = __builtin_amdgcn_readfirstlane(unit.y) & ((1u << kUnitViewShift) - 1u);
     const uint32_t view_s = __builtin_amdgcn_readfirstlane(unit.y) >> kUnitViewShift;
     const int32_t j_lo = (int32_t)(view_s * fc.view_h), j_hi = j_lo + (int32_t)fc.view_h - 1;       // the view's rows
@@ -796,7 +802,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
     const bool alpha_item = (d->flags & kItemAlphaTest) != 0u;       // fragments take the texture alpha test
     gptr_u32 indices = (gptr_u32)d->indices;
     const bool tables_ok = guard(vb + nv <= fc.n_verts, fb.counters, kGuardSetup);
-    const uint32_t chunk_base = blockIdx.x * chunk_tris;
+    const uint32_t chunk_base = unit_index * chunk_tris;
     const uint32_t n_tiles = fc.tiles_x * fc.tiles_y;
     const GlobalSink direct_sink{reinterpret_cast<unsigned long long*>(fb.vis), fc.tiles_x, fc.rank, fc.world, (uint32_t)fb.vis_stride};
     uint32_t valid = 0;
@@ -915,8 +921,8 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
     if (lane == 0) s_valid[wave] = valid;
     __syncthreads();
     if (threadIdx.x == 0) {
-        fb.chunk_count[blockIdx.x] = s_used;
-        fb.chunk_count[fc.n_units + blockIdx.x] = s_valid[0] + s_valid[1] + s_valid[2] + s_valid[3];
+        fb.chunk_count[unit_index] = s_used;
+        fb.chunk_count[fc.n_units + unit_index] = s_valid[0] + s_valid[1] + s_valid[2] + s_valid[3];
     }
 }
 
@@ -2244,11 +2250,11 @@ void launch_setup(const FrameBuffers& fb, const FrameConst& fc, const Capacities
     if (!fc.n_tris) return;
     const bool ms = fc.n_samples == 4u;
     if (fb.alpha_test) {
-        if (ms) hipLaunchKernelGGL((k_setup<true, 4>), dim3(fc.n_units), dim3(256), 0, stream, fb, cap);
-        else hipLaunchKernelGGL((k_setup<true, 1>), dim3(fc.n_units), dim3(256), 0, stream, fb, cap);
+        if (ms) hipLaunchKernelGGL((k_setup<true, 4>), dim3(fc.n_units + kXcds - 1u), dim3(256), 0, stream, fb, cap);
+        else hipLaunchKernelGGL((k_setup<true, 1>), dim3(fc.n_units + kXcds - 1u), dim3(256), 0, stream, fb, cap);
     } else {
-        if (ms) hipLaunchKernelGGL((k_setup<false, 4>), dim3(fc.n_units), dim3(256), 0, stream, fb, cap);
-        else hipLaunchKernelGGL((k_setup<false, 1>), dim3(fc.n_units), dim3(256), 0, stream, fb, cap);
+        if (ms) hipLaunchKernelGGL((k_setup<false, 4>), dim3(fc.n_units + kXcds - 1u), dim3(256), 0, stream, fb, cap);
+        else hipLaunchKernelGGL((k_setup<false, 1>), dim3(fc.n_units + kXcds - 1u), dim3(256), 0, stream, fb, cap);
     }
 }
 void launch_clip(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {

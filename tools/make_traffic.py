@@ -1,0 +1,35 @@
+"""profiles/traffic.json from the summaries of the rocprofv3 --pmc passes (tools/profile_pmc.sh).
+
+usage: python tools/make_traffic.py <fetch.txt> <write.txt> <sq.txt> <profile tag>
+HBM bytes per launch = 2 * FETCH_SIZE * 1000 + WRITE_SIZE * 1000 (FETCH_SIZE and WRITE_SIZE are in KB; on gfx950
+FETCH_SIZE reads half of the bytes fetched: MI355X_MICROARCH.md, HBM section; checked on k_transform, whose
+12 B/vertex of reads are 60.2 MB against FETCH_SIZE 31.3 MB).
+"""
+import ast, json, sys
+
+KEYS = {"k_clear": "clear", "k_cull": "cull", "k_transform": "transform", "k_setup": "setup", "k_clip": "clip",
+        "k_scan_tiles": "scan", "k_bin_fill": "bin", "k_raster": "raster", "k_shade": "shade"}
+
+
+def read(path):
+    out = {}
+    for line in open(path):
+        name, _, rest = line.partition(" {")
+        body = "{" + rest.rsplit("}", 1)[0] + "}"
+        for k, short in KEYS.items():
+            if "rnd::" + k in name:
+                out[short] = ast.literal_eval(body)
+    return out
+
+
+fetch, write, sq, tag = read(sys.argv[1]), read(sys.argv[2]), read(sys.argv[3]), sys.argv[4]
+kernels = {k: int(round(2000.0 * fetch[k]["FETCH_SIZE"] + 1000.0 * write[k]["WRITE_SIZE"])) for k in fetch if k in write}
+valu = {k: int(v["SQ_INSTS_VALU"]) for k, v in sq.items() if v.get("SQ_INSTS_VALU", 0) > 0}
+json.dump({
+    "workload": "c3", "n_gpus": 1,
+    "source": f"rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE and --pmc SQ_INSTS_VALU ... in separate runs (tools/profile_pmc.sh; "
+              f"summaries profiles/{tag}_pmc_fetch_c3.txt, {tag}_pmc_write_c3.txt, {tag}_pmc_sq_c3.txt), mean per launch over the frames of bench.py C3",
+    "correction": "gfx950: FETCH_SIZE (KB) reads 1/2 of the bytes fetched (MI355X_MICROARCH.md, HBM): bytes = 2*FETCH_SIZE*1000 + WRITE_SIZE*1000",
+    "grouping": "one entry per kernel, as bench.py times them (k_clear, k_cull, k_transform, k_setup, k_clip, k_scan_tiles, k_bin_fill, k_raster, k_shade)",
+    "kernels": kernels, "valu_insts": valu}, open("profiles/traffic.json", "w"), indent=2)
+print(json.dumps({"kernels": kernels, "valu_insts": valu}, indent=1))
