@@ -713,7 +713,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         if (want_packed_ && d_packed_.count < (size_t)width_ * height_) throw Error(RND_ERR_UNSUPPORTED, "rnd_render_noalloc: the packed frame has not been allocated for this size");
         const uint64_t need_out = world_ > 1 ? (uint64_t)n_owned_ * kTilePixels * 4 : (uint64_t)width_ * height_ * 4;
         if (noalloc_bytes < need_out) throw Error(RND_ERR_INVALID, "rnd_render_noalloc: output buffer too small");
-        if (1 + (msaa_ - 1) > kPinnedCounterSets) throw Error(RND_ERR_UNSUPPORTED, "rnd_render_noalloc: too many passes");
+        static_assert(kPinnedCounterSets >= 1, "a frame without shadow passes has one counter set, pinned at creation");
     }
     std::vector<ShadowSet> sets(n_sets);
     if (n_sets) {
