@@ -770,7 +770,9 @@ __device__ __forceinline__ void direct_pixel(const DirectTri& d, uint32_t k, con
 // uniform for the whole workgroup, so its fields come in through scalar loads.
 // kAlpha: some draw item of the frame takes the per-fragment texture alpha test (compiled out otherwise)
 // kSamples: 1, or 4 (MSAA): every candidate pixel is tested at its four sample positions, one visibility plane each
-template <bool kAlpha, int kSamples>
+// kViews: the pass has several views (a light's shadow cascades), the unit names its view; the single-view
+// instantiation is the frame's main pass with the view's terms folded away
+template <bool kAlpha, int kSamples, bool kViews>
 __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) {
     FrameConstRef fc = frame_const_ref(fb.frame_const);
     __shared__ uint32_t s_used;         // record slots of this workgroup's chunk handed out so far
@@ -786,8 +788,8 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     const uint2 unit = fb.active_units[unit_index];
     const uint32_t item_s = __builtin_amdgcn_readfirstlane(unit.x), chunk_s = __builtin_amdgcn_readfirstlane(unit.y) & ((1u << kUnitViewShift) - 1u);
-    const uint32_t view_s = __builtin_amdgcn_readfirstlane(unit.y) >> kUnitViewShift;
-    const int32_t j_lo = (int32_t)(view_s * fc.view_h), j_hi = j_lo + (int32_t)fc.view_h - 1;       // the view's rows
+    const uint32_t view_s = kViews ? __builtin_amdgcn_readfirstlane(unit.y) >> kUnitViewShift : 0u;
+    const int32_t j_lo = (int32_t)(view_s * fc.view_h), j_hi = kViews ? j_lo + (int32_t)fc.view_h - 1 : (int32_t)fc.height - 1;       // the view's rows
     const SnapVert* const snap_v = fb.snap + (size_t)view_s * fc.n_verts;
     if (!guard(item_s < fc.n_items, fb.counters, kGuardSetup)) return;      // uniform over the workgroup
     if (threadIdx.x == 0) s_used = 0;
@@ -2249,12 +2251,16 @@ void launch_transform(const FrameBuffers& fb, const FrameConst& fc, hipStream_t 
 void launch_setup(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {
     if (!fc.n_tris) return;
     const bool ms = fc.n_samples == 4u;
-    if (fb.alpha_test) {
-        if (ms) hipLaunchKernelGGL((k_setup<true, 4>), dim3(fc.n_units + kXcds - 1u), dim3(256), 0, stream, fb, cap);
-        else hipLaunchKernelGGL((k_setup<true, 1>), dim3(fc.n_units + kXcds - 1u), dim3(256), 0, stream, fb, cap);
+    const dim3 grid(fc.n_units + kXcds - 1u);
+    if (fc.n_views > 1u) {
+        // a light's cascades: depth only (no alpha test, one sample; visual_server.cpp builds them so)
+        hipLaunchKernelGGL((k_setup<false, 1, true>), grid, dim3(256), 0, stream, fb, cap);
+    } else if (fb.alpha_test) {
+        if (ms) hipLaunchKernelGGL((k_setup<true, 4, false>), grid, dim3(256), 0, stream, fb, cap);
+        else hipLaunchKernelGGL((k_setup<true, 1, false>), grid, dim3(256), 0, stream, fb, cap);
     } else {
-        if (ms) hipLaunchKernelGGL((k_setup<false, 4>), dim3(fc.n_units + kXcds - 1u), dim3(256), 0, stream, fb, cap);
-        else hipLaunchKernelGGL((k_setup<false, 1>), dim3(fc.n_units + kXcds - 1u), dim3(256), 0, stream, fb, cap);
+        if (ms) hipLaunchKernelGGL((k_setup<false, 4, false>), grid, dim3(256), 0, stream, fb, cap);
+        else hipLaunchKernelGGL((k_setup<false, 1, false>), grid, dim3(256), 0, stream, fb, cap);
     }
 }
 void launch_clip(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {
