@@ -132,6 +132,11 @@ struct FrameConst {
     // n_units_view those of one view.  Single-view passes: n_views 1, view_h = height, n_units_view = n_units.
     uint32_t n_views, view_h, view_mask, n_units_view;
     float pv_more[3][16];
+    // World position of a fragment from its interpolated clip x, y, w (k_shade): cam_pos + unproject * (x, y, w),
+    // column-major 3x3 = camera_transform's linear part * diag(1/P00, 1/P11, 1); valid once set_camera has made the
+    // projection a perspective_lh (unproject_ok), where view-space is (x / P00, y / P11, w).
+    float unproject[9];
+    uint32_t unproject_ok;
 };
 constexpr uint32_t kMaxViews = 4;
 constexpr uint32_t kUnitViewShift = 28;        // active_units.y = chunk | view << 28

@@ -1442,38 +1442,82 @@ struct PixelInputs {
 
 // vs_main outputs re-derived for the winning triangle of one pixel, and the ambient term.
 // `d` is wave-uniform (the caller waterfalls over the items of the wave), so its fields come in
-// through scalar loads; per pixel only the index triple and the three 32-byte vertices are gathered.
-template <bool kTextures>
-__device__ __forceinline__ void prepare_pixel(const DrawItem& d, FrameConstRef fc, const float4* __restrict__ clip,
-                                              const TextureDesc* __restrict__ textures, const float* lut, uint32_t id, uint32_t i,
-                                              uint32_t j, PixelInputs& o, FrameCounters* counters) {
+// through scalar loads; per pixel only the index triple, the three clip positions and the corners' attributes are
+// gathered.  Three stages, so that a lane with several pixels of one draw item can have the same stage of all of
+// them in flight at once (the fragment phase is a chain of dependent round trips — visibility word, item, index
+// triple, vertices — and its throughput follows the number of chains in flight: DESIGN.md 5):
+//   frag_indices  issues the index-triple load
+//   frag_fetch    clamps / checks the indices and issues the clip-position and attribute gathers
+//   frag_finish   barycentrics, interpolation, texture, ambient term
+struct FragFetch {
+    uint32_t i0, i1, i2;
+    f32x4 q0, q1, q2;               // clip positions K1 stored for the corners (what setup and raster saw)
+    float n0[3], n1[3], n2[3];      // normals
+    float p0[3], p1[3], p2[3];      // object-space positions (only when the world position cannot come from clip space)
+    float u0, v0, u1, v1, u2, v2;   // uv (textured items)
+};
+
+// The fragment's world position is needed for the lights.  Wherever the clip position IS the projection of that
+// world position (every item but the FixedSize billboards, render_mesh.wgsl:50-52, :65-67) it comes back out of the
+// interpolated clip x, y, w — under perspective_lh the view-space point is (x / P00, y / P11, w): no depth, no
+// cancellation — through fc.unproject (camera_transform's linear part times diag(1/P00, 1/P11, 1)).  The clip
+// positions are gathered anyway for the barycentrics, so the object-space positions are not: a corner is then the
+// 16-byte clip position + the 12-byte normal (+ 8 bytes of uv under a texture) instead of the clip position + the
+// whole 32-byte vertex in two 16-byte gathers, and the loaded data of a pixel is 21 registers instead of 36.
+__device__ __forceinline__ bool world_from_clip(const DrawItem& d, FrameConstRef fc) {
+    return fc.unproject_ok != 0u && (d.flags & kItemBillboardMask) != 2u;      // uniform over the wave
+}
+
+__device__ __forceinline__ void frag_indices(const DrawItem& d, uint32_t id, FragFetch& f, bool& ok) {
     // straight-line: an index that would leave its buffer is clamped and reported, not branched on
     uint32_t t = id - d.tri_base;
-    bool ok = t < d.n_tris;
+    ok = t < d.n_tris;
     t = ok ? t : 0u;
     gptr_u32 ix = (gptr_u32)d.indices + 3ull * t;
-    uint32_t i0 = ix[0], i1 = ix[1], i2 = ix[2];
+    f.i0 = ix[0]; f.i1 = ix[1]; f.i2 = ix[2];
+}
+
+template <bool kTextures>
+__device__ __forceinline__ void frag_fetch(const DrawItem& d, FrameConstRef fc, const float4* __restrict__ clip, FragFetch& f,
+                                           bool ok, FrameCounters* counters) {
     const uint32_t last_v = max(d.n_verts, 1u) - 1u;
-    ok = ok && max(i0, max(i1, i2)) <= last_v && d.n_verts != 0u && d.vert_base + d.n_verts <= fc.n_verts;
-    i0 = min(i0, last_v); i1 = min(i1, last_v); i2 = min(i2, last_v);
+    ok = ok && max(f.i0, max(f.i1, f.i2)) <= last_v && d.n_verts != 0u && d.vert_base + d.n_verts <= fc.n_verts;
+    const uint32_t i0 = min(f.i0, last_v), i1 = min(f.i1, last_v), i2 = min(f.i2, last_v);
     guard(ok, counters, kGuardShade);
     const uint32_t last_c = max(fc.n_verts, 1u) - 1u;
-    gptr_f32x4 vp = (gptr_f32x4)d.verts;
-    const f32x4 a0 = vp[2ull * i0], a1 = vp[2ull * i0 + 1];
-    const f32x4 b0v = vp[2ull * i1], b1v = vp[2ull * i1 + 1];
-    const f32x4 c0v = vp[2ull * i2], c1v = vp[2ull * i2 + 1];
-    rnd_vertex va, vb, vc;
-    va.position[0] = a0.x; va.position[1] = a0.y; va.position[2] = a0.z; va.normal[0] = a0.w; va.normal[1] = a1.x; va.normal[2] = a1.y;
-    vb.position[0] = b0v.x; vb.position[1] = b0v.y; vb.position[2] = b0v.z; vb.normal[0] = b0v.w; vb.normal[1] = b1v.x; vb.normal[2] = b1v.y;
-    vc.position[0] = c0v.x; vc.position[1] = c0v.y; vc.position[2] = c0v.z; vc.normal[0] = c0v.w; vc.normal[1] = c1v.x; vc.normal[2] = c1v.y;
-    // the clip positions K1 stored for these vertices (what setup and raster saw)
+    const bool want_uv = kTextures && d.texture != RND_NONE;
+    if (world_from_clip(d, fc)) {
+        gptr_f32 vf = (gptr_f32)d.verts;
+        gptr_f32 a = vf + 8ull * i0 + 3, b = vf + 8ull * i1 + 3, c = vf + 8ull * i2 + 3;
+        f.n0[0] = a[0]; f.n0[1] = a[1]; f.n0[2] = a[2];
+        f.n1[0] = b[0]; f.n1[1] = b[1]; f.n1[2] = b[2];
+        f.n2[0] = c[0]; f.n2[1] = c[1]; f.n2[2] = c[2];
+        if (want_uv) { f.u0 = a[3]; f.v0 = a[4]; f.u1 = b[3]; f.v1 = b[4]; f.u2 = c[3]; f.v2 = c[4]; }
+    } else {
+        gptr_f32x4 vp = (gptr_f32x4)d.verts;
+        const f32x4 a0 = vp[2ull * i0], a1 = vp[2ull * i0 + 1];
+        const f32x4 b0 = vp[2ull * i1], b1 = vp[2ull * i1 + 1];
+        const f32x4 c0 = vp[2ull * i2], c1 = vp[2ull * i2 + 1];
+        f.p0[0] = a0.x; f.p0[1] = a0.y; f.p0[2] = a0.z; f.n0[0] = a0.w; f.n0[1] = a1.x; f.n0[2] = a1.y;
+        f.p1[0] = b0.x; f.p1[1] = b0.y; f.p1[2] = b0.z; f.n1[0] = b0.w; f.n1[1] = b1.x; f.n1[2] = b1.y;
+        f.p2[0] = c0.x; f.p2[1] = c0.y; f.p2[2] = c0.z; f.n2[0] = c0.w; f.n2[1] = c1.x; f.n2[2] = c1.y;
+        f.u0 = a1.z; f.v0 = a1.w; f.u1 = b1.z; f.v1 = b1.w; f.u2 = c1.z; f.v2 = c1.w;
+    }
     // whole 16-byte loads: z is not used here, and left alone the compiler narrows each load to an 8-byte
     // and a 4-byte one — for divergent gathers the cost is per (lane, instruction), not per byte
     gptr_f32x4 cp = (gptr_f32x4)clip;
-    f32x4 q0 = cp[min(d.vert_base + i0, last_c)], q1 = cp[min(d.vert_base + i1, last_c)], q2 = cp[min(d.vert_base + i2, last_c)];
-    asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2));
-    const float4 c0 = make_float4(q0.x, q0.y, q0.z, q0.w), c1 = make_float4(q1.x, q1.y, q1.z, q1.w),
-                 c2 = make_float4(q2.x, q2.y, q2.z, q2.w);
+    f.q0 = cp[min(d.vert_base + i0, last_c)]; f.q1 = cp[min(d.vert_base + i1, last_c)]; f.q2 = cp[min(d.vert_base + i2, last_c)];
+}
+
+template <bool kTextures>
+__device__ __forceinline__ void frag_finish(const DrawItem& d, FrameConstRef fc, const TextureDesc* __restrict__ textures,
+                                            const float* lut, uint32_t i, uint32_t j, FragFetch& f, PixelInputs& o) {
+    asm volatile("" : "+v"(f.q0), "+v"(f.q1), "+v"(f.q2));
+    const float4 c0 = make_float4(f.q0.x, f.q0.y, f.q0.z, f.q0.w), c1 = make_float4(f.q1.x, f.q1.y, f.q1.z, f.q1.w),
+                 c2 = make_float4(f.q2.x, f.q2.y, f.q2.z, f.q2.w);
+    const bool from_clip = world_from_clip(d, fc);
+    const bool want_uv = kTextures && d.texture != RND_NONE;
+    const float u0 = f.u0, v0 = f.v0, u1 = f.u1, v1 = f.v1, u2 = f.u2, v2 = f.v2;
     // perspective-correct barycentrics: 2D homogeneous edge functions of (x, y, w) at the pixel centre
     // (valid for w <= 0 vertices too)
 #if RND_FAST_SHADE
@@ -1504,16 +1548,25 @@ __device__ __forceinline__ void prepare_pixel(const DrawItem& d, FrameConstRef f
     const float b0 = (float)d0, b1 = (float)d1, b2 = (float)d2;
 #endif
     // attributes, interpolated in object space and transformed once
-    float px = (b0 * va.position[0] + b1 * vb.position[0]) + b2 * vc.position[0];
-    float py = (b0 * va.position[1] + b1 * vb.position[1]) + b2 * vc.position[1];
-    float pz = (b0 * va.position[2] + b1 * vb.position[2]) + b2 * vc.position[2];
-    float nx = (b0 * va.normal[0] + b1 * vb.normal[0]) + b2 * vc.normal[0];
-    float ny = (b0 * va.normal[1] + b1 * vb.normal[1]) + b2 * vc.normal[1];
-    float nz = (b0 * va.normal[2] + b1 * vb.normal[2]) + b2 * vc.normal[2];
-    const float* m = d.world;
-    o.fx = ((m[0] * px + m[4] * py) + m[8] * pz) + m[12];
-    o.fy = ((m[1] * px + m[5] * py) + m[9] * pz) + m[13];
-    o.fz = ((m[2] * px + m[6] * py) + m[10] * pz) + m[14];
+    float nx = (b0 * f.n0[0] + b1 * f.n1[0]) + b2 * f.n2[0];
+    float ny = (b0 * f.n0[1] + b1 * f.n1[1]) + b2 * f.n2[1];
+    float nz = (b0 * f.n0[2] + b1 * f.n1[2]) + b2 * f.n2[2];
+    if (from_clip) {
+        const float kx = (b0 * c0.x + b1 * c1.x) + b2 * c2.x, ky = (b0 * c0.y + b1 * c1.y) + b2 * c2.y,
+                    kw = (b0 * c0.w + b1 * c1.w) + b2 * c2.w;
+        const cptr_f32 q = fc.unproject;
+        o.fx = ((q[0] * kx + q[3] * ky) + q[6] * kw) + fc.cam_pos[0];
+        o.fy = ((q[1] * kx + q[4] * ky) + q[7] * kw) + fc.cam_pos[1];
+        o.fz = ((q[2] * kx + q[5] * ky) + q[8] * kw) + fc.cam_pos[2];
+    } else {
+        const float px = (b0 * f.p0[0] + b1 * f.p1[0]) + b2 * f.p2[0];
+        const float py = (b0 * f.p0[1] + b1 * f.p1[1]) + b2 * f.p2[1];
+        const float pz = (b0 * f.p0[2] + b1 * f.p1[2]) + b2 * f.p2[2];
+        const float* m = d.world;
+        o.fx = ((m[0] * px + m[4] * py) + m[8] * pz) + m[12];
+        o.fy = ((m[1] * px + m[5] * py) + m[9] * pz) + m[13];
+        o.fz = ((m[2] * px + m[6] * py) + m[10] * pz) + m[14];
+    }
     const float* q = d.nrm;
     float gx = (q[0] * nx + q[4] * ny) + q[8] * nz;
     float gy = (q[1] * nx + q[5] * ny) + q[9] * nz;
@@ -1521,8 +1574,7 @@ __device__ __forceinline__ void prepare_pixel(const DrawItem& d, FrameConstRef f
     // base colour = material.base_color * textureSample(...) (render_mesh.wgsl:89, :142); untextured
     // materials bind the 1x1 white texture (visual_server.rs:736)
     float tr = 1.0f, tg = 1.0f, tb = 1.0f;
-    if (kTextures && d.texture != RND_NONE) {        // uniform over the wave (d is)
-        const float u0 = a1.z, v0 = a1.w, u1 = b1v.z, v1 = b1v.w, u2 = c1v.z, v2 = c1v.w;
+    if (want_uv) {        // uniform over the wave (d is)
         const float uu = (b0 * u0 + b1 * u1) + b2 * u2, vv = (b0 * v0 + b1 * v1) + b2 * v2;
         // screen-space uv derivatives for the mip level, analytic: the edge functions are affine in
         // the pixel centre, b_k = e_k / S, so d b_k = (d e_k * S - e_k * dS) / S^2
@@ -1558,6 +1610,18 @@ __device__ __forceinline__ void prepare_pixel(const DrawItem& d, FrameConstRef f
         o.cr = o.br; o.cg = o.bg; o.cb = o.bb;
         o.Nx = o.Ny = o.Nz = o.Vx = o.Vy = o.Vz = 0.0f;
     }
+}
+
+// the three stages in a row, for one pixel
+template <bool kTextures>
+__device__ __forceinline__ void prepare_pixel(const DrawItem& d, FrameConstRef fc, const float4* __restrict__ clip,
+                                              const TextureDesc* __restrict__ textures, const float* lut, uint32_t id, uint32_t i,
+                                              uint32_t j, PixelInputs& o, FrameCounters* counters) {
+    FragFetch f;
+    bool ok;
+    frag_indices(d, id, f, ok);
+    frag_fetch<kTextures>(d, fc, clip, f, ok, counters);
+    frag_finish<kTextures>(d, fc, textures, lut, i, j, f, o);
 }
 
 // compute_light_occlusion (render_mesh.wgsl:184-252): cascade by view depth, biased position
@@ -1735,7 +1799,7 @@ __device__ __forceinline__ GpuLight load_light_uniform(const GpuLight* lights, u
 // and re-used while consecutive samples hold the same triangle — each sample keeps the f16 colour,
 // and the pixel gets their mean (the resolve attachment, visual_server.rs:1134-1153).
 template <int PPT, bool kShadows, int kSamples>
-__global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(FrameBuffers fb) {
+__global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? (kSamples > 1 ? 4 : 5) : 1) void k_shade(FrameBuffers fb) {
     FrameConstRef fc = frame_const_ref(fb.frame_const);
     static_assert(kSamples == 1 || PPT == 2, "the MSAA variant shades one pixel per lane, two of its samples at a time");
     constexpr uint32_t kPix = kSamples > 1 ? 1u : (uint32_t)PPT;        // pixels per lane
@@ -1789,53 +1853,93 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? 5 : 1) void k_shade(
   // MSAA: the lane's two "pixels" are two samples of ONE pixel (samples 0, 1, then 2, 3), so that the light loop runs
   // on the packed pair path as it does for two pixels
   for (int smp = 0; smp < kSamples; smp += (kSamples > 1 ? PPT : 1)) {
-    // phase A: fragment inputs of this lane's pixels
+    // phase A: fragment inputs of this lane's pixels.  The visibility words of all of them first, then — the usual
+    // case: every covered pixel of the wave, over all of the lane's pixels, belongs to ONE draw item — each stage of
+    // the fragment fetch for all pixels before the next stage (PPT <= 2: the loaded data of two pixels is 42
+    // registers), so that the lane's dependent round trips are four (word, item, indices, corners) and not four per pixel.
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    uint32_t id[PPT], pi[PPT], pj[PPT], it[PPT];
+    PixelInputs fresh[PPT];
 #pragma unroll
     for (uint32_t k = 0; k < PPT; ++k) {
         const unsigned long long* vis = vis0 + (size_t)(kSamples > 1 ? (uint32_t)smp + k : 0u) * fb.vis_stride;
         uint32_t local = part + wave * (64u * kPix) + (kSamples > 1 ? 0u : k * 64u) + lane;      // a wave holds 2*kPix consecutive rows
-        uint32_t i = tile_x0 + (local & (kTile - 1)), j = tile_y0 + (local / kTile);
+        pi[k] = tile_x0 + (local & (kTile - 1)); pj[k] = tile_y0 + (local / kTile);
         key[k] = vis[local];
-        uint32_t id = (uint32_t)(key[k] & 0xFFFFFFFFull);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < PPT; ++k) {
+        id[k] = (uint32_t)(key[k] & 0xFFFFFFFFull);
         if constexpr (kSamples > 1) {
             if (smp == 0 && k == 0) key0 = key[k];
             // same triangle as two samples ago: same fragment (shaded at the pixel centre), same colour: px[k] still holds it
-            reuse[k] = smp > 0 && id == prev_id[k];
-            prev_id[k] = id;
+            reuse[k] = smp > 0 && id[k] == prev_id[k];
+            prev_id[k] = id[k];
         }
-        covered[k] = i < fc.width && j < fc.height && id != RND_NONE;
+        covered[k] = pi[k] < fc.width && pj[k] < fc.height && id[k] != RND_NONE;
         if constexpr (kSamples > 1) covered[k] = covered[k] && !reuse[k];
-        if (covered[k] && !guard(id < fc.n_tris, fb.counters, kGuardShade)) covered[k] = false;
+        if (covered[k] && !guard(id[k] < fc.n_tris, fb.counters, kGuardShade)) covered[k] = false;
         // the fragment's inputs go to `fresh`, left unset on lanes without a fragment; the defaults are
         // selected once, after the item paths have merged (initializing up front made every merge point
         // of the branches below re-materialize them)
-        PixelInputs fresh;
-        uint32_t it = 0;
-        if (covered[k]) it = bases_in_lds ? find_item(s_bases, fc.n_items, id) : find_item(fb.tri_bases, fc.n_items, id);
-        const unsigned long long cov = __ballot(covered[k]);
+        it[k] = 0;
+        if (covered[k]) it[k] = bases_in_lds ? find_item(s_bases, fc.n_items, id[k]) : find_item(fb.tri_bases, fc.n_items, id[k]);
+    }
+    bool staged = false;
+    // (not the MSAA variant: it carries both samples' shaded inputs across the sample pairs and has no registers to spare)
+    if constexpr (PPT == 2 && kSamples == 1) {
+        const bool any_k = covered[0] || covered[1];
+        const unsigned long long cov = __ballot(any_k);
         if (cov) {
             uint32_t lead_s;
-            const uint32_t lead = uniform_pick(it, cov, lead_s);
-            if (__ballot(covered[k] && it != lead) == 0ull) {
-                // the usual case: every covered pixel of the wave belongs to one draw item
+            const uint32_t lead = uniform_pick(covered[0] ? it[0] : it[1], cov, lead_s);
+            if (__ballot((covered[0] && it[0] != lead) || (covered[1] && it[1] != lead)) == 0ull) {
                 const DrawItem d = load_item_uniform(fb.items, lead_s);
-                if (covered[k]) prepare_pixel<kShadows>(d, fc, fb.clip, fb.textures, s_lut, id, i, j, fresh, fb.counters);
+                if (world_from_clip(d, fc)) {
+                    staged = true;
+                    FragFetch f[PPT];
+                    bool ok[PPT];
+                    // (a pixel without a fragment fetches the item's first triangle and drops it)
+#pragma unroll
+                    for (uint32_t k = 0; k < PPT; ++k) frag_indices(d, covered[k] ? id[k] : d.tri_base, f[k], ok[k]);
+#pragma unroll
+                    for (uint32_t k = 0; k < PPT; ++k) frag_fetch<kShadows>(d, fc, fb.clip, f[k], ok[k] || !covered[k], fb.counters);
+#pragma unroll
+                    for (uint32_t k = 0; k < PPT; ++k)
+                        if (covered[k]) frag_finish<kShadows>(d, fc, fb.textures, s_lut, pi[k], pj[k], f[k], fresh[k]);
+                }
+            }
+        } else staged = true;        // nothing covered
+    }
+    if (!staged) {
+#pragma unroll
+        for (uint32_t k = 0; k < PPT; ++k) {
+            const unsigned long long cov = __ballot(covered[k]);
+            if (!cov) continue;
+            uint32_t lead_s;
+            const uint32_t lead = uniform_pick(it[k], cov, lead_s);
+            if (__ballot(covered[k] && it[k] != lead) == 0ull) {
+                // every covered pixel of the wave belongs to one draw item
+                const DrawItem d = load_item_uniform(fb.items, lead_s);
+                if (covered[k]) prepare_pixel<kShadows>(d, fc, fb.clip, fb.textures, s_lut, id[k], pi[k], pj[k], fresh[k], fb.counters);
             } else if (covered[k]) {
                 // waterfall: one pass per distinct draw item among the wave's pixels
                 for (unsigned long long pending = __ballot(true); pending;) {
-                    uint32_t cur_s, cur = uniform_pick(it, pending, cur_s);
-                    const bool mine = it == cur;
+                    uint32_t cur_s, cur = uniform_pick(it[k], pending, cur_s);
+                    const bool mine = it[k] == cur;
                     pending &= ~__ballot(mine);
                     if (mine) {
                         const DrawItem d = load_item_uniform(fb.items, cur_s);
-                        prepare_pixel<kShadows>(d, fc, fb.clip, fb.textures, s_lut, id, i, j, fresh, fb.counters);
+                        prepare_pixel<kShadows>(d, fc, fb.clip, fb.textures, s_lut, id[k], pi[k], pj[k], fresh[k], fb.counters);
                     }
                 }
             }
         }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < PPT; ++k) {
         if (kSamples == 1 || !reuse[k]) {
-            if (covered[k]) px[k] = fresh;
+            if (covered[k]) px[k] = fresh[k];
             else {
                 px[k] = PixelInputs{};
                 px[k].cr = fc.clear_hdr[0]; px[k].cg = fc.clear_hdr[1]; px[k].cb = fc.clear_hdr[2];
@@ -2292,6 +2396,12 @@ void launch_shade(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stre
     if (!fb.n_owned) return;
     static const int ppt = [] { const char* e = getenv("RND_SHADE_PPT"); int v = e ? atoi(e) : 2; return (v == 1 || v == 2 || v == 4) ? v : 1; }();
     const bool sh = fb.shadow_sets != nullptr || fb.has_textures;
+    // (experiment aid: unused dynamic LDS per workgroup lowers the occupancy of the shading kernel)
+    static const unsigned lds_pad = [] { const char* e = getenv("RND_SHADE_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
+    if (lds_pad && fc.n_samples != 4 && ppt == 2 && !sh) {
+        hipLaunchKernelGGL((k_shade<2, false, 1>), dim3(fb.n_owned * 2), dim3(256), lds_pad, stream, fb);
+        return;
+    }
     if (fc.n_samples == 4) {
         if (sh) hipLaunchKernelGGL((k_shade<2, true, 4>), dim3(fb.n_owned * 4), dim3(256), 0, stream, fb);
         else hipLaunchKernelGGL((k_shade<2, false, 4>), dim3(fb.n_owned * 4), dim3(256), 0, stream, fb);

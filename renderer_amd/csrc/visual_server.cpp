@@ -596,6 +596,16 @@ void VisualServer::build_frame(std::vector<DrawItem>& items, std::vector<uint32_
     pv.to_cols_array(fc.pv);
     view_.to_cols_array(fc.view);
     fc.cam_pos[0] = camera_transform_.col[3].x; fc.cam_pos[1] = camera_transform_.col[3].y; fc.cam_pos[2] = camera_transform_.col[3].z;
+    {
+        // (doubles, rounded once: the f32 projection entries are the ones the clip positions were made with)
+        // projection_ is a perspective_lh from construction on (SceneUniform defaults), so this always applies
+        const double ia = 1.0 / (double)projection_.col[0].x, ib = 1.0 / (double)projection_.col[1].y;
+        const Vec4 &cx = camera_transform_.col[0], &cy = camera_transform_.col[1], &cz = camera_transform_.col[2];
+        const double q[9] = {cx.x * ia, cx.y * ia, cx.z * ia, cy.x * ib, cy.y * ib, cy.z * ib, cz.x, cz.y, cz.z};
+        bool finite = true;
+        for (int k = 0; k < 9; ++k) { fc.unproject[k] = (float)q[k]; finite = finite && std::isfinite(fc.unproject[k]); }
+        fc.unproject_ok = finite ? 1u : 0u;
+    }
     fc.tone = tone_mapping_;
     std::memcpy(fc.ambient, ambient_light_, 16);
     fc.clear_hdr[0] = round_to_f16(0.02f); fc.clear_hdr[1] = round_to_f16(0.04f); fc.clear_hdr[2] = round_to_f16(0.08f);   // Color::GRUE
