@@ -1421,14 +1421,50 @@ __device__ __forceinline__ float f32_from_ordered(uint32_t u) {
     return __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u);
 }
 // min (or max) over the 64 lanes; every lane must be active.  Result is wave-uniform.
-template <bool kMin>
-__device__ __forceinline__ uint32_t wave_minmax_u32(uint32_t v) {
-#define RND_ROR(n) { const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x120 + n, 0xf, 0xf, false); v = kMin ? min(v, o) : max(v, o); }
-    RND_ROR(1) RND_ROR(2) RND_ROR(4) RND_ROR(8)
-#undef RND_ROR
-    const uint32_t r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
-    const uint32_t r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
-    return kMin ? min(min(r0, r1), min(r2, r3)) : max(max(r0, r1), max(r2, r3));
+// The wave's bounding box: minimum of lo[0..2] and maximum of hi[0..2] over the 64 lanes.  Four rotations inside
+// the rows of 16 lanes, each ONE instruction per value (v_min_f32 / v_max_f32 with the DPP operand), then the four
+// rows through readlane.  Written as assembly: from C++ a step is three instructions (a move with the DPP control,
+// which the compiler does not fold into a float min because it first canonicalizes both operands against
+// signalling NaNs), and round 1's detour through order-preserving integers added conversions both ways: 26 VALU
+// instructions per value against 10.  A VGPR written by a VALU instruction must not be read through DPP for two
+// wait states: the six chains are interleaved, so each value is read five instructions after it was written; the
+// leading s_nop 1 covers whatever wrote the inputs last.
+// Inputs are never NaN here (fragment positions that passed the raster, or the +-3e38 initial values).
+__device__ __forceinline__ void wave_box(float (&lo)[3], float (&hi)[3]) {
+    asm("s_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_f32_dpp %1, %1, %1 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_f32_dpp %2, %2, %2 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %3, %3, %3 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %4, %4, %4 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %5, %5, %5 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_f32_dpp %1, %1, %1 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_f32_dpp %2, %2, %2 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %3, %3, %3 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %4, %4, %4 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %5, %5, %5 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %3, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %4, %4, %4 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %5, %5, %5 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]));
+    auto rows = [](float v, bool is_min) {
+        const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+        const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+        return is_min ? fminf(fminf(r0, r1), fminf(r2, r3)) : fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+    };
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { lo[c] = rows(lo[c], true); hi[c] = rows(hi[c], false); }
 }
 
 struct PixelInputs {
@@ -1957,11 +1993,7 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? (kSamples > 1 ? 4 : 
     // walks the surviving bits in ascending order.  A point light whose sphere misses the box adds
     // exactly zero to every fragment in it (distance > radius discards), so dropping it changes
     // nothing, and the lights keep their original order.
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        lo[c] = f32_from_ordered(wave_minmax_u32<true>(f32_ordered(lo[c])));
-        hi[c] = f32_from_ordered(wave_minmax_u32<false>(f32_ordered(hi[c])));
-    }
+    wave_box(lo, hi);
 #if RND_FAST_SHADE
     PixelPair pp;
     if constexpr (PPT == 2) {
@@ -2356,6 +2388,12 @@ void launch_setup(const FrameBuffers& fb, const FrameConst& fc, const Capacities
     if (!fc.n_tris) return;
     const bool ms = fc.n_samples == 4u;
     const dim3 grid(fc.n_units + kXcds - 1u);
+    // (experiment aid: unused dynamic LDS per workgroup lowers the occupancy of the main pass's setup kernel)
+    static const unsigned lds_pad = [] { const char* e = getenv("RND_SETUP_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
+    if (lds_pad && fc.n_views <= 1u && !fb.alpha_test && !ms) {
+        hipLaunchKernelGGL((k_setup<false, 1, false>), grid, dim3(256), lds_pad, stream, fb, cap);
+        return;
+    }
     if (fc.n_views > 1u) {
         // a light's cascades: depth only (no alpha test, one sample; visual_server.cpp builds them so)
         hipLaunchKernelGGL((k_setup<false, 1, true>), grid, dim3(256), 0, stream, fb, cap);
