@@ -237,7 +237,8 @@ __global__ __launch_bounds__(256) void k_cull(FrameBuffers fb) {
         if (active) {
             fb.active_units[base + (uint32_t)__popcll(am & ((1ull << lane) - 1ull))] = make_uint2(it, chunk | (view << kUnitViewShift));
             if (vb1 - vb0 >= 64u) fb.counters->all_verts = 1u;
-            else for (uint32_t b = vb0; b <= vb1 && b < n_vblocks; ++b) fb.vblock_needed[view * n_vblocks + b] = 1u;
+            // (the flag names a draw item that has vertices in the block: k_transform starts from it instead of searching)
+            else for (uint32_t b = vb0; b <= vb1 && b < n_vblocks; ++b) fb.vblock_needed[view * n_vblocks + b] = it + 1u;
         }
     }
 }
@@ -272,24 +273,40 @@ __global__ __launch_bounds__(256) void k_transform(const DrawItem* __restrict__ 
     static_assert(kVertexBlock == 256, "one workgroup per vertex block");
     const uint32_t view = blockIdx.y;                                    // multi-view passes: one grid row per view
     if (!((fc.view_mask >> view) & 1u)) return;
-    if (!vblock_needed[view * gridDim.x + blockIdx.x] && !counters->all_verts) return;      // no surviving work unit reads this block
+    // the block's flag (written by k_cull: 1 + a draw item that has vertices here) and the "every block" switch together
+    const uint32_t hint_s = __builtin_amdgcn_readfirstlane(vblock_needed[view * gridDim.x + blockIdx.x]);
+    if (!hint_s && !counters->all_verts) return;      // no surviving work unit reads this block
     uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     if (gid >= fc.n_verts) return;
     const size_t out_base = (size_t)view * fc.n_verts;
     const int32_t view_dy = (int32_t)(view * fc.view_h) * kSub;          // the view's rows in the stacked target
-    uint32_t it = find_item(vert_bases, fc.n_items, gid);
-    for (unsigned long long pending = __ballot(true); pending;) {
+    auto transform = [&](const DrawItem& d) {
+        uint32_t v = gid - d.vert_base;
+        float x = ((gptr_f32)d.px)[v], y = ((gptr_f32)d.py)[v], z = ((gptr_f32)d.pz)[v];
+        float4 c = clip_position(d, view_pv(fc, view), x, y, z);
+        clip[out_base + gid] = c;
+        const SnapVert sv = snap_and_classify(c, 0.5f * (float)fc.width, 0.5f * (float)fc.view_h);
+        *reinterpret_cast<uint4*>(snap + out_base + gid) = make_uint4((uint32_t)sv.x, (uint32_t)(sv.y + view_dy), __float_as_uint(sv.z), sv.code);
+    };
+    // The usual block lies inside one draw item, the one the flag names: no search (the binary search over the items'
+    // vertex bases is a chain of dependent loads, which is what this kernel's 64-vertex waves cannot hide).
+    unsigned long long pending = __ballot(true);
+    if (hint_s && hint_s <= fc.n_items) {
+        const DrawItem d = load_item_uniform(items, hint_s - 1u);
+        const bool mine = gid - d.vert_base < d.n_verts;         // (unsigned: also false below the item's first vertex)
+        if (mine) transform(d);
+        pending &= ~__ballot(mine);
+    }
+    if (!pending) return;
+    const bool left = (pending >> lane_id()) & 1ull;
+    uint32_t it = left ? find_item(vert_bases, fc.n_items, gid) : 0u;
+    while (pending) {
         uint32_t cur_s, cur = uniform_pick(it, pending, cur_s);
-        const bool mine = it == cur;
+        const bool mine = left && it == cur;
         pending &= ~__ballot(mine);
         if (mine) {
             const DrawItem d = load_item_uniform(items, cur_s);
-            uint32_t v = gid - d.vert_base;
-            float x = ((gptr_f32)d.px)[v], y = ((gptr_f32)d.py)[v], z = ((gptr_f32)d.pz)[v];
-            float4 c = clip_position(d, view_pv(fc, view), x, y, z);
-            clip[out_base + gid] = c;
-            const SnapVert sv = snap_and_classify(c, 0.5f * (float)fc.width, 0.5f * (float)fc.view_h);
-            *reinterpret_cast<uint4*>(snap + out_base + gid) = make_uint4((uint32_t)sv.x, (uint32_t)(sv.y + view_dy), __float_as_uint(sv.z), sv.code);
+            transform(d);
         }
     }
 }
