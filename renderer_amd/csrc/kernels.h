@@ -19,6 +19,7 @@ struct FrameBuffers {
     const uint32_t* tri_bases;      // n_items + 1
     const GpuLight* lights;
     const ShadowSet* shadow_sets;   // indexed by GpuLight::shadow_index
+    uint32_t n_shadow_sets;
     const TextureDesc* textures;    // indexed by DrawItem::texture
     const float* srgb_lut;          // 512 entries: [0,256) sRGB8 -> linear, [256,512) alpha8 -> [0,1]
     uint32_t alpha_test;            // some draw item has kItemAlphaTest: launch the raster variants with the test

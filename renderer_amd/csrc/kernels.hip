@@ -1725,6 +1725,64 @@ __device__ __forceinline__ float light_occlusion(const ShadowSet* __restrict__ s
     return occlusion / 9.0f;
 }
 
+// The same look-up for the two fragments of a lane, straight-line: both fragments' nine taps are in flight together
+// (18 four-byte loads of the depth halves), the cascade's matrix and layer pointer come from the LDS copy of the
+// set, and the early exits are predicates (a lane without a lit fragment, or facing away, computes on whatever it
+// holds and its result is dropped; every address is clamped into the map).  Same arithmetic per fragment as
+// light_occlusion, in the same order.
+constexpr uint32_t kLdsShadowSets = 8;
+struct ShadowProbe { float u, v, frag_depth; const uint32_t* map; bool facing; };
+__device__ __forceinline__ ShadowProbe shadow_probe(const ShadowSet& S, FrameConstRef fc, float fx, float fy, float fz, float nx, float ny,
+                                                    float nz, float lx, float ly, float lz) {
+    ShadowProbe q;
+    q.facing = !(dot3(nx, ny, nz, lx, ly, lz) > 0.0f);
+    const float view_depth = ((fc.view[2] * fx + fc.view[6] * fy) + fc.view[10] * fz) + fc.view[14];
+    uint32_t layer; float bias_mod;
+    if (view_depth <= 0.05f * 100.0f) { layer = 0; bias_mod = 0.03f; }
+    else if (view_depth <= 0.1f * 100.0f) { layer = 1; bias_mod = 0.05f; }
+    else if (view_depth <= 0.3f * 100.0f) { layer = 2; bias_mod = 0.1f; }
+    else { layer = 3; bias_mod = 0.2f; }
+    const float ox = ((-lx) * 0.3f + nx * 0.8f) * bias_mod, oy = ((-ly) * 0.3f + ny * 0.8f) * bias_mod,
+                oz = ((-lz) * 0.3f + nz * 0.8f) * bias_mod;
+    const float bx = fx + ox, by = fy + oy, bz = fz + oz;
+    const float* m = S.world_to_light[layer < 2u ? layer : 2u];
+    const float cx = ((m[0] * bx + m[4] * by) + m[8] * bz) + m[12] * 1.0f;
+    const float cy = ((m[1] * bx + m[5] * by) + m[9] * bz) + m[13] * 1.0f;
+    const float cz = ((m[2] * bx + m[6] * by) + m[10] * bz) + m[14] * 1.0f;
+    const float cw = ((m[3] * bx + m[7] * by) + m[11] * bz) + m[15] * 1.0f;
+    const float qx = cx / cw, qy = cy / cw, qz = cz / cw;
+    q.u = (qx + 1.0f) * 0.5f; q.v = 1.0f - (qy + 1.0f) * 0.5f;
+    q.frag_depth = fminf(fmaxf(qz, 0.0f), 1.0f);
+    q.map = reinterpret_cast<const uint32_t*>(S.layers[layer]);
+    return q;
+}
+__device__ __forceinline__ void shadow_taps_issue(const ShadowProbe& q, uint32_t (&tap)[9], uint32_t& inside) {
+    const float texel = 1.0f / (float)kShadowSize;
+    constexpr uint32_t kTilesX = kShadowSize / kTile;
+    inside = 0;
+#pragma unroll
+    for (int x = -1; x <= 1; ++x)
+#pragma unroll
+        for (int y = -1; y <= 1; ++y) {
+            const int k = (x + 1) * 3 + (y + 1);
+            const float su = q.u + (float)x * texel, sv = q.v + (float)y * texel;
+            if (su >= 0.0f && su < 1.0f && sv >= 0.0f && sv < 1.0f) inside |= 1u << k;
+            const uint32_t ix = min((uint32_t)fmaxf(floorf(su * (float)kShadowSize), 0.0f), kShadowSize - 1u);
+            const uint32_t iy = min((uint32_t)fmaxf(floorf(sv * (float)kShadowSize), 0.0f), kShadowSize - 1u);
+            const uint32_t at = ((iy / kTile) * kTilesX + ix / kTile) * kTilePixels + ((iy % kTile) * kTile + ix % kTile);
+            tap[k] = q.map[2u * at + 1u];       // the depth half of the visibility word
+        }
+}
+__device__ __forceinline__ float shadow_taps_count(const ShadowProbe& q, const uint32_t (&tap)[9], uint32_t inside) {
+    float occlusion = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {           // (same order as the loops of light_occlusion: x outer, y inner)
+        const float occluder = ((inside >> k) & 1u) ? __uint_as_float(tap[k]) : 1.0f;
+        if (q.frag_depth > occluder) occlusion += 1.0f;
+    }
+    return q.facing ? occlusion / 9.0f : 0.0f;
+}
+
 // fs_main_blinn_phong for one light and one fragment (render_mesh.wgsl:134-181, :256-281)
 template <bool kShadows>
 __device__ __forceinline__ void add_light(const GpuLight& L, PixelInputs& p, const ShadowSet* __restrict__ sets,
@@ -1794,7 +1852,7 @@ __device__ __forceinline__ float shadow_term(const ShadowSet* __restrict__ sets,
 // (five packed operations less than normalizing o first; N.V is per fragment, outside the light loop)
 template <bool kShadows>
 __device__ __forceinline__ void add_light_pair(const GpuLight& L, PixelPair& p, const ShadowSet* __restrict__ sets,
-                                               FrameConstRef fc) {
+                                               const ShadowSet* lds_sets, FrameConstRef fc) {
 #pragma clang fp contract(fast)
     f32x2 ox, oy, oz, inv_d, dist, inten;
     if (L.kind == RND_LIGHT_DIRECTIONAL) {
@@ -1802,8 +1860,19 @@ __device__ __forceinline__ void add_light_pair(const GpuLight& L, PixelPair& p, 
         inv_d = dist = splat2(1.0f);
         float i0 = L.color[3], i1 = L.color[3];
         if constexpr (kShadows) {
-            if (p.lit0) i0 = L.color[3] * (1.0f - shadow_term(sets, L, fc, p.fx.x, p.fy.x, p.fz.x, p.Nx.x, p.Ny.x, p.Nz.x));
-            if (p.lit1) i1 = L.color[3] * (1.0f - shadow_term(sets, L, fc, p.fx.y, p.fy.y, p.fz.y, p.Nx.y, p.Ny.y, p.Nz.y));
+            if ((uint32_t)L.shadow_index >= kLdsShadowSets) {       // (uniform over the wave) none, or beyond the LDS copy: one by one
+                if (p.lit0) i0 = L.color[3] * (1.0f - shadow_term(sets, L, fc, p.fx.x, p.fy.x, p.fz.x, p.Nx.x, p.Ny.x, p.Nz.x));
+                if (p.lit1) i1 = L.color[3] * (1.0f - shadow_term(sets, L, fc, p.fx.y, p.fy.y, p.fz.y, p.Nx.y, p.Ny.y, p.Nz.y));
+            } else {
+                const ShadowSet& S = lds_sets[L.shadow_index];
+                const ShadowProbe q0 = shadow_probe(S, fc, p.fx.x, p.fy.x, p.fz.x, p.Nx.x, p.Ny.x, p.Nz.x, L.dir[0], L.dir[1], L.dir[2]);
+                const ShadowProbe q1 = shadow_probe(S, fc, p.fx.y, p.fy.y, p.fz.y, p.Nx.y, p.Ny.y, p.Nz.y, L.dir[0], L.dir[1], L.dir[2]);
+                uint32_t t0[9], t1[9], in0, in1;
+                shadow_taps_issue(q0, t0, in0);
+                shadow_taps_issue(q1, t1, in1);
+                i0 = L.color[3] * (1.0f - shadow_taps_count(q0, t0, in0));
+                i1 = L.color[3] * (1.0f - shadow_taps_count(q1, t1, in1));
+            }
         }
         inten = (f32x2){i0, i1};
     } else {
@@ -1861,6 +1930,13 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? (kSamples > 1 ? 4 : 
     __shared__ float s_lut[kShadows ? 512 : 1];     // texel decode table (see FetchSrgb8), full variant only
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if constexpr (kShadows) { s_lut[tid] = fb.srgb_lut[tid]; s_lut[256u + tid] = fb.srgb_lut[256u + tid]; }
+    __shared__ ShadowSet s_sets[kShadows ? kLdsShadowSets : 1];      // the first cascade sets (matrices, layer pointers), full variant only
+    if constexpr (kShadows) {
+        const uint32_t n_words = min(fb.n_shadow_sets, kLdsShadowSets) * (uint32_t)(sizeof(ShadowSet) / 4);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(fb.shadow_sets);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(s_sets);
+        for (uint32_t k = tid; k < n_words; k += 256u) dst[k] = src[k];
+    }
     const bool bases_in_lds = fc.n_items <= kLdsItems;
     if (bases_in_lds)
         for (uint32_t k = tid; k <= fc.n_items; k += 256u) s_bases[k] = fb.tri_bases[k];
@@ -2052,7 +2128,7 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? (kSamples > 1 ? 4 : 
                     // (the last light is loaded a second time rather than branching around the load)
                     const uint32_t ni = more ? group + (uint32_t)(__ffsll((long long)km) - 1) : 0u;
                     const GpuLight nxt = load_light_uniform(fb.lights, __builtin_amdgcn_readfirstlane(ni));
-                    add_light_pair<kShadows>(cur, pp, fb.shadow_sets, fc);
+                    add_light_pair<kShadows>(cur, pp, fb.shadow_sets, s_sets, fc);
                     if (!more) break;
                     km &= km - 1ull;
                     cur = nxt;
@@ -2083,7 +2159,7 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? (kSamples > 1 ? 4 : 
                 }
 #endif
 #if RND_FAST_SHADE
-                if constexpr (PPT == 2) { add_light_pair<kShadows>(L, pp, fb.shadow_sets, fc); continue; }
+                if constexpr (PPT == 2) { add_light_pair<kShadows>(L, pp, fb.shadow_sets, s_sets, fc); continue; }
 #endif
 #pragma unroll
                 for (uint32_t k = 0; k < PPT; ++k)
