@@ -1978,6 +1978,7 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? (kSamples > 1 ? 4 : 
     bool reuse[PPT];
 #pragma unroll
     for (uint32_t k = 0; k < PPT; ++k) { prev_id[k] = RND_NONE; reuse[k] = false; }
+    float keep[PPT][3] = {};        // MSAA: the colour each of the lane's two samples was shaded to in the previous pair
     unsigned long long key0 = 0;
   // MSAA: the lane's two "pixels" are two samples of ONE pixel (samples 0, 1, then 2, 3), so that the light loop runs
   // on the packed pair path as it does for two pixels
@@ -2015,8 +2016,7 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? (kSamples > 1 ? 4 : 
         if (covered[k]) it[k] = bases_in_lds ? find_item(s_bases, fc.n_items, id[k]) : find_item(fb.tri_bases, fc.n_items, id[k]);
     }
     bool staged = false;
-    // (not the MSAA variant: it carries both samples' shaded inputs across the sample pairs and has no registers to spare)
-    if constexpr (PPT == 2 && kSamples == 1) {
+    if constexpr (PPT == 2) {
         const bool any_k = covered[0] || covered[1];
         const unsigned long long cov = __ballot(any_k);
         if (cov) {
@@ -2067,12 +2067,13 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? (kSamples > 1 ? 4 : 
     }
 #pragma unroll
     for (uint32_t k = 0; k < PPT; ++k) {
-        if (kSamples == 1 || !reuse[k]) {
-            if (covered[k]) px[k] = fresh[k];
-            else {
-                px[k] = PixelInputs{};
-                px[k].cr = fc.clear_hdr[0]; px[k].cg = fc.clear_hdr[1]; px[k].cb = fc.clear_hdr[2];
-            }
+        // (every field is set here on every path: of a sample pair only the three colours in `keep` live on to the next)
+        if (covered[k]) px[k] = fresh[k];
+        else {
+            px[k] = PixelInputs{};
+            const bool again = kSamples > 1 && reuse[k];
+            px[k].cr = again ? keep[k][0] : fc.clear_hdr[0]; px[k].cg = again ? keep[k][1] : fc.clear_hdr[1];
+            px[k].cb = again ? keep[k][2] : fc.clear_hdr[2];
         }
         if (covered[k]) {
             if (px[k].lit) {
@@ -2178,6 +2179,7 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? (kSamples > 1 ? 4 : 
     if constexpr (kSamples > 1) {
 #pragma unroll
         for (uint32_t k = 0; k < PPT; ++k) {
+            keep[k][0] = px[k].cr; keep[k][1] = px[k].cg; keep[k][2] = px[k].cb;
             sum_r = sum_r + round_f16(px[k].cr); sum_g = sum_g + round_f16(px[k].cg); sum_b = sum_b + round_f16(px[k].cb);
         }
     }
