@@ -409,7 +409,14 @@ __device__ __forceinline__ f32x4 texture_bilinear(const TextureDesc& t, uint32_t
     const float x = u * (float)wl - 0.5f, y = v * (float)hl - 0.5f;
     const float xf = floorf(x), yf = floorf(y);
     const float fx = x - xf, fy = y - yf;
+    // Repeat: the texel index modulo the level's size.  For a power-of-two size (the rule; uniform over the wave) the
+    // float form is exact for every finite f — f / n and n * floor(.) are scalings, the difference is below n — and
+    // replaces a 64-bit integer remainder (software, a hundred instructions per coordinate).
     auto wrap = [](float f, uint32_t n) {
+        if ((n & (n - 1u)) == 0u) {
+            const float fn = (float)n;
+            return (uint32_t)(f - fn * floorf(f / fn));
+        }
         long long k = (long long)f % (long long)n;
         return (uint32_t)(k < 0 ? k + (long long)n : k);
     };
