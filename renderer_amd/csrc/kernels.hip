@@ -73,6 +73,20 @@ __device__ __forceinline__ bool owns_tile(uint32_t tx, uint32_t ty, uint32_t ran
     return ((ty / kOwnerGroup) % world) == rank;   // full-width stripes of kOwnerGroup tile rows
 }
 
+// 24-bit signed multiply (+ 32-bit add): full-rate instructions that take the low 24 bits of their operands as they
+// are.  Written as assembly because the library routine behind __mul24 sign-extends each operand first (a v_bfe_i32
+// apiece that the multiply does not need); plain VALU instructions, no hazards of their own.
+__device__ __forceinline__ int32_t mul24(int32_t a, int32_t b) {
+    int32_t r;
+    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ int32_t mad24(int32_t a, int32_t b, int32_t c) {
+    int32_t r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
     return (ax * bx + ay * by) + az * bz;
 }
@@ -573,9 +587,9 @@ __device__ __forceinline__ void raster_small(const SetupRecord& r, int32_t i0, i
     const int32_t px = i0 * kSub + kSub / 2, py = j0 * kSub + kSub / 2;
     // callers pass records with flag bit 0 (bbox below 64 px) and pixels of that bbox: every factor
     // is below 2^15 in magnitude, so the full-rate 24-bit multiply is exact
-    int32_t r0 = __mul24(ex0, py - r.y2) - __mul24(ey0, px - r.x2);
-    int32_t r1 = __mul24(ex1, py - r.y0) - __mul24(ey1, px - r.x0);
-    int32_t r2 = __mul24(ex2, py - r.y1) - __mul24(ey2, px - r.x1);
+    int32_t r0 = mul24(ex0, py - r.y2) - mul24(ey0, px - r.x2);
+    int32_t r1 = mul24(ex1, py - r.y0) - mul24(ey1, px - r.x0);
+    int32_t r2 = mul24(ex2, py - r.y1) - mul24(ey2, px - r.x1);
     const SampleSteps<int32_t> st = sample_steps<int32_t>(ex0, ey0, ex1, ey1, ex2, ey2);
     for (int32_t j = j0; j <= j1; ++j) {
         int32_t w0 = r0, w1 = r1, w2 = r2;
@@ -709,7 +723,7 @@ __device__ __forceinline__ void setup_triangle(bool live, const SnapVert& v0, co
 struct DirectTri {                  // 20 dwords = 5 x 16 B
     int32_t r0, r1, r2;             // edge functions at the bbox's first pixel centre
     int32_t sx0, sx1, sx2;          // ex * 256: step per pixel row
-    int32_t sy0, sy1, sy2;          // ey * 256: step per pixel column (subtracted)
+    int32_t nsy0, nsy1, nsy2;       // -ey * 256: step per pixel column
     uint32_t shape;                 // bbox width | pixel count << 8 | top-left bias bits << 16 | alpha test << 19
     float z0, dz1, dz2, inv_area;
     uint32_t id;
@@ -732,11 +746,11 @@ __device__ __forceinline__ DirectTri make_direct(const SetupRecord& r, const Til
     const uint32_t b2 = ((-ey2 > 0) || (ey2 == 0 && ex2 > 0)) ? 0u : 1u;
     const int32_t px = t.i0 * kSub + kSub / 2, py = t.j0 * kSub + kSub / 2;
     DirectTri d;
-    d.r0 = __mul24(ex0, py - r.y2) - __mul24(ey0, px - r.x2);
-    d.r1 = __mul24(ex1, py - r.y0) - __mul24(ey1, px - r.x0);
-    d.r2 = __mul24(ex2, py - r.y1) - __mul24(ey2, px - r.x1);
+    d.r0 = mul24(ex0, py - r.y2) - mul24(ey0, px - r.x2);
+    d.r1 = mul24(ex1, py - r.y0) - mul24(ey1, px - r.x0);
+    d.r2 = mul24(ex2, py - r.y1) - mul24(ey2, px - r.x1);
     d.sx0 = ex0 * kSub; d.sx1 = ex1 * kSub; d.sx2 = ex2 * kSub;
-    d.sy0 = ey0 * kSub; d.sy1 = ey1 * kSub; d.sy2 = ey2 * kSub;
+    d.nsy0 = -ey0 * kSub; d.nsy1 = -ey1 * kSub; d.nsy2 = -ey2 * kSub;
     const uint32_t w = (uint32_t)(t.i1 - t.i0 + 1), h = (uint32_t)(t.j1 - t.j0 + 1);
     d.shape = w | ((w * h) << 8) | (b0 << 16) | (b1 << 17) | (b2 << 18) | (((r.flags >> 1) & 1u) << 19);
     d.z0 = r.z0; d.dz1 = r.dz1; d.dz2 = r.dz2; d.inv_area = r.inv_area;
@@ -764,15 +778,15 @@ __device__ __forceinline__ void direct_pixel(const DirectTri& d, uint32_t k, con
     // 1 ulp of the approximate reciprocal (absolute error below 1e-5 at these magnitudes)
     const uint32_t dj = (uint32_t)(((float)k + 0.5f) * d.inv_w);
     const uint32_t di = k - dj * w;
-    const int32_t w0 = d.r0 + __mul24((int32_t)dj, d.sx0) - __mul24((int32_t)di, d.sy0);
-    const int32_t w1 = d.r1 + __mul24((int32_t)dj, d.sx1) - __mul24((int32_t)di, d.sy1);
-    const int32_t w2 = d.r2 + __mul24((int32_t)dj, d.sx2) - __mul24((int32_t)di, d.sy2);
+    const int32_t w0 = mad24((int32_t)di, d.nsy0, mad24((int32_t)dj, d.sx0, d.r0));
+    const int32_t w1 = mad24((int32_t)di, d.nsy1, mad24((int32_t)dj, d.sx1, d.r1));
+    const int32_t w2 = mad24((int32_t)di, d.nsy2, mad24((int32_t)dj, d.sx2, d.r2));
     const int32_t b0 = (int32_t)((d.shape >> 16) & 1u), b1 = (int32_t)((d.shape >> 17) & 1u), b2 = (int32_t)((d.shape >> 18) & 1u);
     const uint32_t i = (d.origin & 0xFFFFu) + di, j = (d.origin >> 16) + dj;
     SampleSteps<int32_t> st{};
     if constexpr (kSamples > 1)     // (sx = ex * 256, sy = ey * 256: the shifts are exact)
-        st = sample_steps<int32_t>(d.sx0 >> kSubpixelBits, d.sy0 >> kSubpixelBits, d.sx1 >> kSubpixelBits, d.sy1 >> kSubpixelBits,
-                          d.sx2 >> kSubpixelBits, d.sy2 >> kSubpixelBits);
+        st = sample_steps<int32_t>(d.sx0 >> kSubpixelBits, -(d.nsy0 >> kSubpixelBits), d.sx1 >> kSubpixelBits, -(d.nsy1 >> kSubpixelBits),
+                          d.sx2 >> kSubpixelBits, -(d.nsy2 >> kSubpixelBits));
     pixel_samples<kSamples, int32_t>(w0, w1, w2, b0, b1, b2, st,
         [&] { if constexpr (kAlpha) return !((d.shape >> 19) & 1u) || alpha_pass(fb, fc, d.id, i, j); return true; },
         [&](int32_t s1, int32_t s2, uint32_t smp) {
@@ -1214,9 +1228,9 @@ __device__ __forceinline__ void raster_wave(const SetupRecord& r, int32_t i0, in
     const int32_t px = (i0 + lx) * kSub + kSub / 2, py = (j0 + ly) * kSub + kSub / 2;
     edge_t r0, r1, r2;
     if constexpr (kNarrow) {
-        r0 = __mul24(ex0, py - r.y2) - __mul24(ey0, px - r.x2);
-        r1 = __mul24(ex1, py - r.y0) - __mul24(ey1, px - r.x0);
-        r2 = __mul24(ex2, py - r.y1) - __mul24(ey2, px - r.x1);
+        r0 = mul24(ex0, py - r.y2) - mul24(ey0, px - r.x2);
+        r1 = mul24(ex1, py - r.y0) - mul24(ey1, px - r.x0);
+        r2 = mul24(ex2, py - r.y1) - mul24(ey2, px - r.x1);
     } else {
         r0 = (long long)ex0 * (py - r.y2) - (long long)ey0 * (px - r.x2);
         r1 = (long long)ex1 * (py - r.y0) - (long long)ey1 * (px - r.x0);
