@@ -1586,6 +1586,11 @@ __device__ __forceinline__ void frag_fetch(const DrawItem& d, FrameConstRef fc, 
 template <bool kTextures>
 __device__ __forceinline__ void frag_finish(const DrawItem& d, FrameConstRef fc, const TextureDesc* __restrict__ textures,
                                             const float* lut, uint32_t i, uint32_t j, FragFetch& f, PixelInputs& o) {
+#if RND_FAST_SHADE
+    // products and sums of the interpolation and of the two transforms may contract to FMAs here, as in the light loop:
+    // colour parity is a tolerance (the coverage / depth arithmetic of the raster kernels never contracts)
+#pragma clang fp contract(fast)
+#endif
     asm volatile("" : "+v"(f.q0), "+v"(f.q1), "+v"(f.q2));
     const float4 c0 = make_float4(f.q0.x, f.q0.y, f.q0.z, f.q0.w), c1 = make_float4(f.q1.x, f.q1.y, f.q1.z, f.q1.w),
                  c2 = make_float4(f.q2.x, f.q2.y, f.q2.z, f.q2.w);
