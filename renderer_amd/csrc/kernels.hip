@@ -873,6 +873,14 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
             const SnapVert v0{(int32_t)q0.x, (int32_t)q0.y, __uint_as_float(q0.z), q0.w};
             const SnapVert v1{(int32_t)q1.x, (int32_t)q1.y, __uint_as_float(q1.z), q1.w};
             const SnapVert v2{(int32_t)q2.x, (int32_t)q2.y, __uint_as_float(q2.z), q2.w};
+            {
+                // a wave whose 64 triangles are all rejected, back-facing or degenerate (the far side of a closed mesh is
+                // long runs of them) stops here: the same outcode and area terms as setup_triangle / make_record
+                const uint32_t any = v0.code | v1.code | v2.code, all = v0.code & v1.code & v2.code;
+                const bool go = in && idx_ok && !(any & kOutNonFinite) && !(all & kOutPlanes);
+                const long long A2 = (long long)(v1.x - v0.x) * (v2.y - v0.y) - (long long)(v2.x - v0.x) * (v1.y - v0.y);
+                if (!__ballot(go && ((any & kOutNeedsClip) != 0u || A2 < 0))) continue;
+            }
             setup_triangle(in && idx_ok, v0, v1, v2, gid, fc, j_lo, j_hi, rec, tr, emit, need_clip);
             if (alpha_item) rec.flags |= 2u;
         }
