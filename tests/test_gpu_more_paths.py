@@ -337,3 +337,37 @@ def test_light_set_between_reset_scene_and_set_camera():
             vs.set_mesh_instance(nid, t, handles[m])
         vs.render()
     assert_parity(gpu, cpu, min_covered=15000, shadow_taps=True)
+
+
+def test_ten_shadowed_suns_use_both_shadow_lookup_paths():
+    """The shading kernel keeps the first eight cascade sets in LDS and looks both fragments of a lane up together; the
+    sets beyond that go through the one-fragment routine in global memory (kLdsShadowSets, kernels.hip).  Ten
+    directional lights exercise both in one frame, and a textured, non-power-of-two image next to them the integer
+    Repeat wrap."""
+    s = shadow_scene()
+    rng = np.random.default_rng(5)
+    for k in range(9):
+        t = from_rotation_x(0.7 + 0.08 * k) @ from_rotation_y(-0.6 + 0.15 * k)
+        c = rng.uniform(0.2, 1.0, 3)
+        s.lights.append((200 + k, t, Light.directional().with_color(Color(float(c[0]), float(c[1]), float(c[2]), 0.4))))
+    px = rng.integers(0, 256, (48, 80, 4)).astype(np.uint8)      # 80 x 48: neither size a power of two
+    px[..., 3] = 255
+    image = Image(80, 48, px)            # (one level: the reference generates mips only for square power-of-two images)
+    pair = []
+    for make in (lambda: VisualServer(s.width, s.height, device=0), lambda: oracle_server(s.width, s.height)):
+        vs = make()
+        tex = vs.asset_server.add(image)
+        mat = vs.asset_server.add(Material(base_color=Color(0.9, 0.95, 1.0, 1.0), base_color_image=tex))
+        for m in s.meshes:
+            for sub in m.submeshes:
+                sub.material = mat
+        s.populate(vs)
+        vs.render()
+        pair.append(vs)
+    gpu, cpu = pair
+    assert sum(1 for _, _, l in s.lights if l.kind_id() == 0) == 10
+    assert_parity(gpu, cpu, min_covered=15000, shadow_taps=True)
+    assert gpu.frame_stats()["overflow"] == 0
+    for m in s.meshes:
+        for sub in m.submeshes:
+            sub.material = None
