@@ -900,10 +900,18 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
         // small triangles: rasterize now, no record
         const bool direct = emit && (rec.flags & 1u) &&
                             (uint32_t)(tr.i1 - tr.i0 + 1) * (uint32_t)(tr.j1 - tr.j0 + 1) <= fb.direct_pixels;
-        // the wave's direct triangles are compacted into LDS and re-dealt four lanes each
+        // The wave's direct triangles are compacted into LDS and re-dealt 2, 4 or 8 lanes each, by the size of the
+        // wave's bboxes: a pass costs its entry fetch plus one round per ceil(pixels / lanes) of its largest bbox, so
+        // sub-pixel triangles (C3, C5: one or two pixel centres per bbox) want many triangles per pass and ~20-pixel
+        // bboxes (C4) many lanes per triangle.  Measured with the width fixed at 2 / 4 / 8: k_setup at C3 0.102 / 0.107 /
+        // 0.137 ms, C2 0.038 / 0.034 / 0.034, C4 3.44 / 2.51 / 2.40, C5 0.667 / 0.694 / 0.785.
         auto run_direct = [&](bool has, const TileRect& t, int smp) {
             const unsigned long long dm = __ballot(has);
             if (!dm) return;
+            const uint32_t box = (uint32_t)(t.i1 - t.i0 + 1) * (uint32_t)(t.j1 - t.j0 + 1);
+            const uint32_t n_all = (uint32_t)__popcll(dm), n_3 = (uint32_t)__popcll(__ballot(has && box >= 3u)),
+                           n_13 = (uint32_t)__popcll(__ballot(has && box >= 13u));
+            const uint32_t sh = n_13 * 2u > n_all ? 3u : (n_3 * 3u > n_all ? 2u : 1u);       // log2(lanes per triangle), uniform
             if (has) {
                 const DirectTri dt = make_direct(rec, t, smp);
                 const uint4* src = reinterpret_cast<const uint4*>(&dt);
@@ -916,15 +924,15 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const uint32_t n_direct = (uint32_t)__popcll(dm);
-            for (uint32_t base = 0; base < n_direct; base += 16u) {
-                const uint32_t which = base + (lane >> 2);
+            for (uint32_t base = 0; base < n_direct; base += 64u >> sh) {
+                const uint32_t which = base + (lane >> sh);
                 if (which < n_direct) {
                     DirectTri dt;
                     uint4* dst = reinterpret_cast<uint4*>(&dt);
                     const uint4* src = s_direct[wave][which];
                     dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3]; dst[4] = src[4];
                     const uint32_t npix = (dt.shape >> 8) & 255u;
-                    for (uint32_t k = lane & 3u; k < npix; k += 4u) direct_pixel<kAlpha, 1, (kSamples > 1)>(dt, k, direct_sink, fb, fc);
+                    for (uint32_t k = lane & ((1u << sh) - 1u); k < npix; k += 1u << sh) direct_pixel<kAlpha, 1, (kSamples > 1)>(dt, k, direct_sink, fb, fc);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
