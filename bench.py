@@ -116,10 +116,11 @@ def algorithmic_bytes(stats, n_visible_tris):
         "setup": 12 * nt + 16 * nv + 8 * p + 56 * min(nbin, nrec),
         "bin": 12 * min(nbin, nrec) + 4 * nbin,               # (tile word, bin pos) + tile offset in, bin entries out
         "raster": 52 * nbin + 16 * min(p, 1024 * nbin),       # entries + records per bin entry, visibility tile in and out
-        # vis in, rgba8 out, gathers: the index triple per visible triangle, and per distinct corner the 16-byte clip
-        # position + the 12-byte normal (the object-space positions are not read since round 2: the world position
-        # comes from the clip coordinates; the bench scenes are untextured, so no uv either)
-        "shade": 8 * p + 4 * p + 12 * n_visible_tris + 28 * min(3 * n_visible_tris, nv),
+        # vis in, rgba8 out, gathers: SURVEY.md 8d's K4 figure — the index triple per visible triangle and, per distinct
+        # corner, the 32-byte source vertex + the 16-byte clip position.  (Since round 2 the kernel needs only 28 of
+        # those 48 bytes — clip position + normal; the world position comes from the clip coordinates — but the vertex's
+        # 12 normal bytes still arrive in its whole cache line: the PMC traffic is unchanged)
+        "shade": 8 * p + 4 * p + 12 * n_visible_tris + 48 * min(3 * n_visible_tris, nv),
     }
 
 
