@@ -298,7 +298,8 @@ __global__ __launch_bounds__(256) void k_transform(const DrawItem* __restrict__ 
         uint32_t v = gid - d.vert_base;
         float x = ((gptr_f32)d.px)[v], y = ((gptr_f32)d.py)[v], z = ((gptr_f32)d.pz)[v];
         float4 c = clip_position(d, view_pv(fc, view), x, y, z);
-        clip[out_base + gid] = c;
+        // (kept for the shading kernel; a depth-only pass has no reader for it — the clipper makes its own — and passes null)
+        if (clip) clip[gid] = c;
         const SnapVert sv = snap_and_classify(c, 0.5f * (float)fc.width, 0.5f * (float)fc.view_h);
         *reinterpret_cast<uint4*>(snap + out_base + gid) = make_uint4((uint32_t)sv.x, (uint32_t)(sv.y + view_dy), __float_as_uint(sv.z), sv.code);
     };
@@ -1028,8 +1029,12 @@ __global__ __launch_bounds__(256) void k_clip(FrameBuffers fb, Capacities cap) {
             gptr_u32 ix = (gptr_u32)d.indices + 3ull * t;
             alpha = (d.flags & kItemAlphaTest) ? 2u : 0u;
             ClipVert a[12], b[12];
+            // the clip positions again from the object-space positions, by K1's own routine (the same operations on the
+            // same inputs: the same bits).  Triangles that reach the clipper are rare, and this way the depth-only
+            // passes (a light's four cascade views) do not store 16 bytes per vertex and view that nothing else reads.
             for (int k = 0; k < 3; ++k) {
-                float4 c = fb.clip[(size_t)view * fc.n_verts + d.vert_base + ix[k]];
+                const uint32_t v = min(ix[k], max(d.n_verts, 1u) - 1u);
+                const float4 c = clip_position(d, view_pv(fc, view), ((gptr_f32)d.px)[v], ((gptr_f32)d.py)[v], ((gptr_f32)d.pz)[v]);
                 a[k] = ClipVert{c.x, c.y, c.z, c.w};
             }
             int cnt = 3;

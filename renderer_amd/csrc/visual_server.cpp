@@ -774,7 +774,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     const size_t n_unit_words = std::max<size_t>(2 * (size_t)fc.n_units * n_views_max, 2);
     const size_t n_view_verts = std::max<size_t>((size_t)fc.n_verts * n_views_max, 1);
     if (noalloc) {
-        bp.clip = arena.take<float4>(n_view_verts); bp.snap = arena.take<SnapVert>(n_view_verts);
+        bp.clip = arena.take<float4>(std::max<size_t>(fc.n_verts, 1)); bp.snap = arena.take<SnapVert>(n_view_verts);
         bp.records = arena.take<SetupRecord>(cap_.records); bp.tilewords = arena.take<uint32_t>(2 * (size_t)cap_.records);
         bp.clip_queue = arena.take<uint32_t>(2 * (size_t)cap_.clip_queue);      // triangle ids, then their views
         bp.chunk_count = arena.take<uint32_t>(n_unit_words);
@@ -788,7 +788,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         bp.counters = arena.take<FrameCounters>(n_counter_sets);
         bp.vis = arena.take<uint64_t>(n_tiles * kTilePixels * msaa_);
     } else {
-        d_clip_[p].ensure(n_view_verts);
+        d_clip_[p].ensure(std::max<size_t>(fc.n_verts, 1));        // (the main pass's only: shading reads it)
         d_snap_.ensure(n_view_verts);
         d_records_.ensure(cap_.records); d_tilewords_.ensure(2 * (size_t)cap_.records);
         d_clip_queue_.ensure(2 * (size_t)cap_.clip_queue);
@@ -993,6 +993,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         }
         FrameBuffers sfb = fb;
         sfb.items = reinterpret_cast<const DrawItem*>(tb + off_si); sfb.lights = nullptr; sfb.shadow_sets = nullptr; sfb.alpha_test = 0;
+        sfb.clip = nullptr;        // depth only: nothing reads clip positions (k_transform skips the store)
         sfb.counters = bp.counters + 1 + k;
         sfb.launch_order = order.ptr; sfb.n_owned = n_order;
         sfb.vis = shadow_layers_[p][k].ptr;         // the four layers, contiguous: the stacked target's tiles
