@@ -1470,16 +1470,7 @@ __device__ __forceinline__ uint32_t srgb8_f(float lin) {
 #endif
 }
 
-// Monotone map f32 -> u32 (and back) so float min/max run as integer min/max over DPP row
-// rotations: no NaN canonicalization, one instruction per step.
-__device__ __forceinline__ uint32_t f32_ordered(float f) {
-    const uint32_t b = __float_as_uint(f);
-    return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
-}
-__device__ __forceinline__ float f32_from_ordered(uint32_t u) {
-    return __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u);
-}
-// min (or max) over the 64 lanes; every lane must be active.  Result is wave-uniform.
+// Every lane must be active; the results are wave-uniform.
 // The wave's bounding box: minimum of lo[0..2] and maximum of hi[0..2] over the 64 lanes.  Four rotations inside
 // the rows of 16 lanes, each ONE instruction per value (v_min_f32 / v_max_f32 with the DPP operand), then the four
 // rows through readlane.  Written as assembly: from C++ a step is three instructions (a move with the DPP control,
