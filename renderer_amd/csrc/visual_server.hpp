@@ -192,7 +192,7 @@ private:
     };
     EventSet event_sets_[kEventSets];
     uint32_t event_next_ = 0;
-    static constexpr uint64_t kTimingStride = 16;     // a timed frame runs un-overlapped (two serialization points): keep them rare
+    static constexpr uint64_t kTimingStride = 256;    // a timed frame runs un-overlapped (two serialization points): keep them rare
     // instantiated HIP graphs of the frame's kernel sequence, keyed by the launches' by-value arguments
     static constexpr int kGraphSlots = 8;      // the key cycles through 3 staging blocks x 2 frame parities
     struct CachedGraph { std::vector<uint8_t> key; hipGraphExec_t exec = nullptr; };

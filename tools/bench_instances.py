@@ -30,7 +30,7 @@ for _ in range(steps):
 t1 = time.perf_counter()
 vs.finish()
 t2 = time.perf_counter()
-mean, _ = vs.mean_timings()
+mean, _ = vs.timed_means(drv.frame)
 print(f"{m} {kind} instances: {steps / (t2 - t0):.1f} frames/s, host enqueue {(t1 - t0) / steps * 1e3:.3f} ms/frame", {k: round(v, 4) for k, v in mean.items()})
 # the same frames with the instance list handed over in one call
 import ctypes as C

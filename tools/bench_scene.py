@@ -20,5 +20,5 @@ for _ in range(steps):
     drv.frame()
 vs.finish()
 dt = time.perf_counter() - t0
-mean, n = vs.mean_timings()
+mean, n = vs.timed_means(drv.frame)
 print(f"{name} {w}x{h}: {steps / dt:.1f} frames/s", {k: round(v, 4) for k, v in mean.items()}, vs.frame_stats())

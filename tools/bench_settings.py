@@ -27,5 +27,5 @@ for _ in range(steps):
     drv.frame()
 vs.finish()
 dt = time.perf_counter() - t0
-mean, _ = vs.mean_timings()
+mean, _ = vs.timed_means(drv.frame)
 print(f"{name} msaa {msaa} factor {factor} lights {len(scene.lights)}: {steps / dt:.1f} frames/s", {k: round(v, 4) for k, v in mean.items()})

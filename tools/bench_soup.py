@@ -21,5 +21,5 @@ for _ in range(n):
     vs.render()
 vs.finish()
 dt = time.perf_counter() - t0
-mean, _ = vs.mean_timings()
+mean, _ = vs.timed_means(vs.render)
 print(f"soup {w}x{h} {nm}x{nt} size {size}: {n / dt:.1f} frames/s", {k: round(v, 4) for k, v in mean.items()}, vs.frame_stats())

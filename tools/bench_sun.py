@@ -32,5 +32,5 @@ for _ in range(steps):
     drv.frame()
 vs.finish()
 dt = time.perf_counter() - t0
-mean, _ = vs.mean_timings()
+mean, _ = vs.timed_means(drv.frame)
 print(f"{name} + sun{' + texture' if textured else ''}: {steps / dt:.1f} frames/s", {k: round(v, 4) for k, v in mean.items()})

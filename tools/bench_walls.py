@@ -24,5 +24,5 @@ for _ in range(steps):
     vs.render()
 vs.finish()
 dt = time.perf_counter() - t0
-mean, _ = vs.mean_timings()
+mean, _ = vs.timed_means(vs.render)
 print(f"{n} screen-filling quads: {steps / dt:.1f} frames/s", {k: round(v, 4) for k, v in mean.items()}, vs.frame_stats())
