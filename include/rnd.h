@@ -261,7 +261,7 @@ int rnd_last_timings(rnd_ctx* ctx, rnd_timings* out);
  * the context's stream around each kernel; harvested without stalling the frames in flight).
  * Waits for the frames still in flight.  reset != 0 clears the accumulators afterwards. */
 int rnd_mean_timings(rnd_ctx* ctx, rnd_timings* mean, uint32_t* n_frames, int reset);
-/* Timing events are normally recorded on a sample of the frames only (every 16th: a timed frame runs without the
+/* Timing events are normally recorded on a sample of the frames only (the first four, then every 256th: a timed frame runs without the
  * overlap with its neighbours, so that its kernel durations are its own).  rnd_time_frames makes the next n frames
  * timed ones; rnd_timing_stats is rnd_mean_timings with the per-kernel maximum beside the mean (either may be NULL). */
 int rnd_time_frames(rnd_ctx* ctx, uint32_t n);
