@@ -1461,10 +1461,12 @@ __device__ __forceinline__ float rsqrt_f(float x) {
 }
 __device__ __forceinline__ uint32_t srgb8_f(float lin) {
 #if RND_FAST_SHADE
-    float x = fminf(fmaxf(lin, 0.0f), 1.0f);
-    float y = (x <= 0.0031308f) ? 12.92f * x : 1.055f * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (1.0f / 2.4f)) - 0.055f;
-    int v = (int)(y * 255.0f + 0.5f);
-    return (uint32_t)min(max(v, 0), 255);
+    // floor(255 y + 0.5) with the OETF's two branches folded into one FMA each: 255 * (1.055 p - 0.055) + 0.5 and
+    // 255 * 12.92 x + 0.5.  x is clamped to [0, 1] (NaN -> 0), so the result is in [0, 255] without a second clamp.
+    const float x = fminf(fmaxf(lin, 0.0f), 1.0f);
+    const float p = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (1.0f / 2.4f));
+    const float v = (x <= 0.0031308f) ? fmaf(x, 255.0f * 12.92f, 0.5f) : fmaf(p, 255.0f * 1.055f, 0.5f - 255.0f * 0.055f);
+    return (uint32_t)(int)v;
 #else
     return srgb8(lin);
 #endif
