@@ -1692,16 +1692,25 @@ __device__ __forceinline__ void frag_finish(const DrawItem& d, FrameConstRef fc,
     o.br = d.base_color[0] * tr; o.bg = d.base_color[1] * tg; o.bb = d.base_color[2] * tb;
     o.lit = !(d.flags & kItemUnlit);
     if (o.lit) {
-        float ar = fc.ambient[0] * fc.ambient[3], ag = fc.ambient[1] * fc.ambient[3], ab = fc.ambient[2] * fc.ambient[3];
-        o.cr = o.br * ar; o.cg = o.bg * ag; o.cb = o.bb * ab;
         float inv_n = rsqrt_f(dot3(gx, gy, gz, gx, gy, gz));
         o.Nx = gx * inv_n; o.Ny = gy * inv_n; o.Nz = gz * inv_n;
+    } else {
+        o.Nx = o.Ny = o.Nz = 0.0f;
+    }
+}
+
+// what frag_finish leaves out, so that a finished pixel waits for its neighbour in ten registers, not sixteen: the
+// ambient term and the unit vector to the camera
+__device__ __forceinline__ void complete_inputs(PixelInputs& o, FrameConstRef fc) {
+    if (o.lit) {
+        float ar = fc.ambient[0] * fc.ambient[3], ag = fc.ambient[1] * fc.ambient[3], ab = fc.ambient[2] * fc.ambient[3];
+        o.cr = o.br * ar; o.cg = o.bg * ag; o.cb = o.bb * ab;
         float vx = fc.cam_pos[0] - o.fx, vy = fc.cam_pos[1] - o.fy, vz = fc.cam_pos[2] - o.fz;
         float inv_v = rsqrt_f(dot3(vx, vy, vz, vx, vy, vz));
         o.Vx = vx * inv_v; o.Vy = vy * inv_v; o.Vz = vz * inv_v;
     } else {
         o.cr = o.br; o.cg = o.bg; o.cb = o.bb;
-        o.Nx = o.Ny = o.Nz = o.Vx = o.Vy = o.Vz = 0.0f;
+        o.Vx = o.Vy = o.Vz = 0.0f;
     }
 }
 
@@ -2108,7 +2117,7 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? (kSamples > 1 ? 4 : 
 #pragma unroll
     for (uint32_t k = 0; k < PPT; ++k) {
         // (every field is set here on every path: of a sample pair only the three colours in `keep` live on to the next)
-        if (covered[k]) px[k] = fresh[k];
+        if (covered[k]) { px[k] = fresh[k]; complete_inputs(px[k], fc); }
         else {
             px[k] = PixelInputs{};
             const bool again = kSamples > 1 && reuse[k];
@@ -2569,24 +2578,25 @@ void launch_shade(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stre
     if (!fb.n_owned) return;
     static const int ppt = [] { const char* e = getenv("RND_SHADE_PPT"); int v = e ? atoi(e) : 2; return (v == 1 || v == 2 || v == 4) ? v : 1; }();
     const bool sh = fb.shadow_sets != nullptr || fb.has_textures;
-    // (experiment aid: unused dynamic LDS per workgroup lowers the occupancy of the shading kernel)
-    static const unsigned lds_pad = [] { const char* e = getenv("RND_SHADE_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
-    if (lds_pad && fc.n_samples != 4 && ppt == 2 && !sh) {
-        hipLaunchKernelGGL((k_shade<2, false, 1>), dim3(fb.n_owned * 2), dim3(256), lds_pad, stream, fb);
-        return;
-    }
+    // Unused dynamic LDS per workgroup.  The plain variant (72 VGPRs, 20 KB of LDS) is limited to seven workgroups a CU by
+    // its registers and to eight by its LDS; claiming 2 KB more makes LDS say seven as well, and with that the next frame's
+    // geometry kernels, which run beside this one, interleave better: 3110 -> 3320 frames/s at C3, this kernel's own time
+    // unchanged.  RND_SHADE_LDS_PAD overrides it for every variant (the occupancy experiments).
+    static const int lds_env = [] { const char* e = getenv("RND_SHADE_LDS_PAD"); return e ? atoi(e) : -1; }();
+    const bool plain = fc.n_samples != 4 && ppt == 2 && !sh;
+    const unsigned pad = lds_env >= 0 ? (unsigned)lds_env : (plain ? 2048u : 0u);
     if (fc.n_samples == 4) {
-        if (sh) hipLaunchKernelGGL((k_shade<2, true, 4>), dim3(fb.n_owned * 4), dim3(256), 0, stream, fb);
-        else hipLaunchKernelGGL((k_shade<2, false, 4>), dim3(fb.n_owned * 4), dim3(256), 0, stream, fb);
+        if (sh) hipLaunchKernelGGL((k_shade<2, true, 4>), dim3(fb.n_owned * 4), dim3(256), pad, stream, fb);
+        else hipLaunchKernelGGL((k_shade<2, false, 4>), dim3(fb.n_owned * 4), dim3(256), pad, stream, fb);
     } else if (ppt == 4) {
-        if (sh) hipLaunchKernelGGL((k_shade<4, true, 1>), dim3(fb.n_owned), dim3(256), 0, stream, fb);
-        else hipLaunchKernelGGL((k_shade<4, false, 1>), dim3(fb.n_owned), dim3(256), 0, stream, fb);
+        if (sh) hipLaunchKernelGGL((k_shade<4, true, 1>), dim3(fb.n_owned), dim3(256), pad, stream, fb);
+        else hipLaunchKernelGGL((k_shade<4, false, 1>), dim3(fb.n_owned), dim3(256), pad, stream, fb);
     } else if (ppt == 2) {
-        if (sh) hipLaunchKernelGGL((k_shade<2, true, 1>), dim3(fb.n_owned * 2), dim3(256), 0, stream, fb);
-        else hipLaunchKernelGGL((k_shade<2, false, 1>), dim3(fb.n_owned * 2), dim3(256), 0, stream, fb);
+        if (sh) hipLaunchKernelGGL((k_shade<2, true, 1>), dim3(fb.n_owned * 2), dim3(256), pad, stream, fb);
+        else hipLaunchKernelGGL((k_shade<2, false, 1>), dim3(fb.n_owned * 2), dim3(256), pad, stream, fb);
     } else {
-        if (sh) hipLaunchKernelGGL((k_shade<1, true, 1>), dim3(fb.n_owned * 4), dim3(256), 0, stream, fb);
-        else hipLaunchKernelGGL((k_shade<1, false, 1>), dim3(fb.n_owned * 4), dim3(256), 0, stream, fb);
+        if (sh) hipLaunchKernelGGL((k_shade<1, true, 1>), dim3(fb.n_owned * 4), dim3(256), pad, stream, fb);
+        else hipLaunchKernelGGL((k_shade<1, false, 1>), dim3(fb.n_owned * 4), dim3(256), pad, stream, fb);
     }
 }
 void launch_extract(const uint64_t* vis, const TileRef* order, uint32_t n_owned, const FrameConst& fc, float* depth,
