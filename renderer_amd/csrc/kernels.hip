@@ -67,6 +67,15 @@ __device__ __forceinline__ uint32_t find_item(const uint32_t* __restrict__ bases
     return lo;
 }
 
+// The same for one wave-uniform id and n <= 64, by all lanes at once: lane k looks at [bases[k], bases[k+1]) (bases has
+// n + 1 entries), the one lane that holds the id answers.  n when no lane does (id >= bases[n]).
+__device__ __forceinline__ uint32_t find_item_wave(const uint32_t* __restrict__ bases, uint32_t n, uint32_t id_uniform, uint32_t lane) {
+    bool in = false;
+    if (lane < n) in = bases[lane] <= id_uniform && id_uniform < bases[lane + 1];
+    const unsigned long long m = __ballot(in);
+    return m ? (uint32_t)__ffsll((long long)m) - 1u : n;
+}
+
 __device__ __forceinline__ bool owns_tile(uint32_t tx, uint32_t ty, uint32_t rank, uint32_t world) {
     if (world <= 1) return true;
     (void)tx;
@@ -1970,7 +1979,7 @@ __device__ __forceinline__ GpuLight load_light_uniform(const GpuLight* lights, u
 // and re-used while consecutive samples hold the same triangle — each sample keeps the f16 colour,
 // and the pixel gets their mean (the resolve attachment, visual_server.rs:1134-1153).
 template <int PPT, bool kShadows, int kSamples>
-__global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? (kSamples > 1 ? 4 : 5) : 1) void k_shade(FrameBuffers fb) {
+__global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? (kSamples > 1 ? 4 : 7) : 1) void k_shade(FrameBuffers fb) {
     FrameConstRef fc = frame_const_ref(fb.frame_const);
     static_assert(kSamples == 1 || PPT == 2, "the MSAA variant shades one pixel per lane, two of its samples at a time");
     constexpr uint32_t kPix = kSamples > 1 ? 1u : (uint32_t)PPT;        // pixels per lane
@@ -2062,18 +2071,29 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? (kSamples > 1 ? 4 : 
         // selected once, after the item paths have merged (initializing up front made every merge point
         // of the branches below re-materialize them)
         it[k] = 0;
-        if (covered[k]) it[k] = bases_in_lds ? find_item(s_bases, fc.n_items, id[k]) : find_item(fb.tri_bases, fc.n_items, id[k]);
     }
     bool staged = false;
     if constexpr (PPT == 2) {
         const bool any_k = covered[0] || covered[1];
         const unsigned long long cov = __ballot(any_k);
         if (cov) {
+            // the draw item of the wave's first fragment, looked up once for the wave (all lanes compare one range of
+            // the base table each; tables of more than 64 items: that lane's own binary search), then every other
+            // fragment is tested against its triangle range: two instructions a pixel instead of a search
             uint32_t lead_s;
-            const uint32_t lead = uniform_pick(covered[0] ? it[0] : it[1], cov, lead_s);
-            if (__ballot((covered[0] && it[0] != lead) || (covered[1] && it[1] != lead)) == 0ull) {
+            if (bases_in_lds && fc.n_items <= 64u) {
+                uint32_t id_s;
+                uniform_pick(covered[0] ? id[0] : id[1], cov, id_s);
+                lead_s = find_item_wave(s_bases, fc.n_items, id_s, lane);
+                asm volatile("" : "+s"(lead_s));
+            } else {
+                const uint32_t some = covered[0] ? id[0] : id[1];
+                uniform_pick(any_k ? (bases_in_lds ? find_item(s_bases, fc.n_items, some) : find_item(fb.tri_bases, fc.n_items, some)) : 0u, cov, lead_s);
+            }
+            if (lead_s < fc.n_items) {
                 const DrawItem d = load_item_uniform(fb.items, lead_s);
-                if (world_from_clip(d, fc)) {
+                const bool others = (covered[0] && id[0] - d.tri_base >= d.n_tris) || (covered[1] && id[1] - d.tri_base >= d.n_tris);
+                if (__ballot(others) == 0ull && world_from_clip(d, fc)) {
                     staged = true;
                     FragFetch f[PPT];
                     bool ok[PPT];
@@ -2090,6 +2110,9 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? (kSamples > 1 ? 4 : 
         } else staged = true;        // nothing covered
     }
     if (!staged) {
+#pragma unroll
+        for (uint32_t k = 0; k < PPT; ++k)
+            if (covered[k]) it[k] = bases_in_lds ? find_item(s_bases, fc.n_items, id[k]) : find_item(fb.tri_bases, fc.n_items, id[k]);
 #pragma unroll
         for (uint32_t k = 0; k < PPT; ++k) {
             const unsigned long long cov = __ballot(covered[k]);
