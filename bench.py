@@ -28,7 +28,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
-N_SIMDS, VALU_CLOCK_HZ = 256 * 4, 2.4e9      # a wave64 VALU instruction occupies one 16-lane SIMD for 4 cycles
+N_SIMDS, VALU_CLOCK_HZ = 256 * 4, 2.4e9      # a wave64 VALU instruction takes a SIMD's 32 lanes for 2 cycles (MI355X_MICROARCH.md)
 TIMED_FRAMES = 16          # frames with events around every kernel, after the throughput loop (outside `elapsed`)
 
 WORKLOADS = {
@@ -328,8 +328,9 @@ def main():
                  "frac": round(ach / HBM_PEAK_GBS, 4) if ach else None, "traffic": tj.get("kernels", {}).get(k)}
             insts = tj.get("valu_insts", {}).get(k)
             if insts and mean[k + "_ms"] > 0:
-                # what actually bounds these kernels: share of the SIMDs' issue cycles spent on VALU instructions
-                r["valu_busy"] = round(insts * 4 / (N_SIMDS * VALU_CLOCK_HZ * mean[k + "_ms"] * 1e-3), 3)
+                # share of the SIMDs' cycles spent on VALU instructions (2 cycles each; 4, the figure of the 16-lane
+                # SIMDs before gfx950, would put k_shade's 103.6 M instructions at 103 % of its own duration)
+                r["valu_busy"] = round(insts * 2 / (N_SIMDS * VALU_CLOCK_HZ * mean[k + "_ms"] * 1e-3), 3)
             return r
         result = {
             "metric": "Mtriangles/s", "value": round(n_tris * fps / 1e6, 2), "unit": "Mtriangles/s",
