@@ -106,6 +106,8 @@ typedef const __attribute__((address_space(1))) uint32_t* gptr_u32;
 typedef const __attribute__((address_space(1))) float* gptr_f32;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) f32x4* gptr_f32x4;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) f32x2* gptr_f32x2;
 
 // Waterfall helper: picks the value of `v` held by the first lane of `pending` as a scalar.
 // Two things make the obvious `cur = readfirstlane(v); if (cur == v) {...}` loop unsafe: the
@@ -139,8 +141,9 @@ __device__ __forceinline__ DrawItem load_item_uniform(const DrawItem* items, uin
     return d;
 }
 
-// vs_main's clip position (render_mesh.wgsl:42-82).  K1 stores it; the shading kernel re-derives
-// it from the object-space position it gathers anyway: same inputs, same operations, same bits.
+// vs_main's clip position (render_mesh.wgsl:42-82).  K1 keeps only what triangle setup reads of it (the snapped
+// vertex); the clipper, the alpha test and the shading kernel re-derive it from the object-space position they
+// gather anyway: same inputs, same operations, same bits (the shading kernel's default is a cheaper form: corner_clip).
 // projection * view of view `v` of the pass (FrameConst: multi-view passes)
 __device__ __forceinline__ cptr_f32 view_pv(FrameConstRef fc, uint32_t v) { return v == 0u ? fc.pv : fc.pv_more[v - 1u]; }
 
@@ -164,7 +167,7 @@ __device__ __forceinline__ float4 clip_position(const DrawItem& d, cptr_f32 p, f
 
 // ------------------------------------------------------------------------------------------
 // K1: vertex transform.  One thread per (draw item, vertex); positions are read from three SoA
-// streams (4 B/lane, fully coalesced), the clip position is written as one 16-byte store per lane.
+// streams (4 B/lane, fully coalesced), the snapped vertex is written as one 16-byte store per lane.
 // The draw item is made wave-uniform (waterfall over the rare waves that straddle two items) so
 // its matrices come in through scalar loads.
 // ------------------------------------------------------------------------------------------
@@ -307,7 +310,8 @@ __global__ __launch_bounds__(256) void k_transform(const DrawItem* __restrict__ 
         uint32_t v = gid - d.vert_base;
         float x = ((gptr_f32)d.px)[v], y = ((gptr_f32)d.py)[v], z = ((gptr_f32)d.pz)[v];
         float4 c = clip_position(d, view_pv(fc, view), x, y, z);
-        // (kept for the shading kernel; a depth-only pass has no reader for it — the clipper makes its own — and passes null)
+        // (kept for the shading kernel of frames with few vertices per pixel; null otherwise and in depth-only passes:
+        // see corner_clip)
         if (clip) clip[gid] = c;
         const SnapVert sv = snap_and_classify(c, 0.5f * (float)fc.width, 0.5f * (float)fc.view_h);
         *reinterpret_cast<uint4*>(snap + out_base + gid) = make_uint4((uint32_t)sv.x, (uint32_t)(sv.y + view_dy), __float_as_uint(sv.z), sv.code);
@@ -472,7 +476,7 @@ __device__ __forceinline__ f32x4 texture_sample(const TextureDesc& t, Lut lut, f
 // The alpha test of a textured fragment (render_mesh.wgsl:89-92, :142-146: base = material.base_color *
 // textureSample(...); base.a < 0.5 discards), for draw items whose texture has alpha below 1.  Runs
 // in the raster stage, before the fragment may enter the (depth, id) resolve: the triangle's clip
-// positions and uv are fetched again from the id, barycentrics and the uv footprint as at shade time.
+// positions (made again from the vertices) and uv are fetched from the id, barycentrics and the uv footprint as at shade time.
 __device__ __forceinline__ bool alpha_pass(const FrameBuffers& fb, FrameConstRef fc, uint32_t id, uint32_t i, uint32_t j) {
     const uint32_t it = find_item(fb.tri_bases, fc.n_items, id);
     const DrawItem& d = fb.items[it];
@@ -481,12 +485,14 @@ __device__ __forceinline__ bool alpha_pass(const FrameBuffers& fb, FrameConstRef
     uint32_t t = id - d.tri_base;
     if (t >= d.n_tris || d.n_verts == 0u) return true;
     gptr_u32 ix = (gptr_u32)d.indices + 3ull * t;
-    const uint32_t last_v = d.n_verts - 1u, last_c = max(fc.n_verts, 1u) - 1u;
+    const uint32_t last_v = d.n_verts - 1u;
     const uint32_t i0 = min(ix[0], last_v), i1 = min(ix[1], last_v), i2 = min(ix[2], last_v);
     gptr_f32x4 vp = (gptr_f32x4)d.verts;
+    const f32x4 a0 = vp[2ull * i0], b0v = vp[2ull * i1], c0v = vp[2ull * i2];
     const f32x4 a1 = vp[2ull * i0 + 1], b1v = vp[2ull * i1 + 1], c1v = vp[2ull * i2 + 1];
-    const float4 c0 = fb.clip[min(d.vert_base + i0, last_c)], c1 = fb.clip[min(d.vert_base + i1, last_c)],
-                 c2 = fb.clip[min(d.vert_base + i2, last_c)];
+    // (the corners' clip positions by K1's routine from the positions the vertices bring along: the bits K1 made)
+    const float4 c0 = clip_position(d, fc.pv, a0.x, a0.y, a0.z), c1 = clip_position(d, fc.pv, b0v.x, b0v.y, b0v.z),
+                 c2 = clip_position(d, fc.pv, c0v.x, c0v.y, c0v.z);
     const float u0 = a1.z, v0 = a1.w, u1 = b1v.z, v1 = b1v.w, u2 = c1v.z, v2 = c1v.w;
     const float xn = fmaf((float)i + 0.5f, fc.ndc_step_xf, -1.0f), yn = fmaf(-((float)j + 0.5f), fc.ndc_step_yf, 1.0f);
     const float px0 = fmaf(-xn, c0.w, c0.x), py0 = fmaf(-yn, c0.w, c0.y);
@@ -1548,9 +1554,9 @@ struct PixelInputs {
 //   frag_finish   barycentrics, interpolation, texture, ambient term
 struct FragFetch {
     uint32_t i0, i1, i2;
-    f32x4 q0, q1, q2;               // clip positions K1 stored for the corners (what setup and raster saw)
+    f32x4 q0, q1, q2;               // clip positions K1 stored for the corners (frames that keep them)
+    float p0[3], p1[3], p2[3];      // object-space positions (frames without stored clip positions: see corner_clip)
     float n0[3], n1[3], n2[3];      // normals
-    float p0[3], p1[3], p2[3];      // object-space positions (only when the world position cannot come from clip space)
     float u0, v0, u1, v1, u2, v2;   // uv (textured items)
 };
 
@@ -1565,6 +1571,21 @@ __device__ __forceinline__ bool world_from_clip(const DrawItem& d, FrameConstRef
     return fc.unproject_ok != 0u && (d.flags & kItemBillboardMask) != 2u;      // uniform over the wave
 }
 
+// The clip position of a corner (x, y, w: depth is not needed at shade time).  Two sources, chosen per frame on the
+// host (VisualServer::enqueue_frame, `store_clip`):
+//   * K1 stored it (fb.clip): a second divergent 16-byte gather per corner next to the 12-byte normal.  Costs K1 16 of
+//     its 44 bytes per vertex; right when the frame has few vertices per pixel (C3: K1 +7 us, k_shade -18 us).
+//   * made again from the object-space position that the corner's 32-byte vertex brings along with its normal, by K1's
+//     own routine, operation by operation (clip_position: the bits setup and raster saw), 36 instructions per corner.
+//     Right when vertices outnumber the pixels (C5: 50 M vertices, transform 0.36 -> 0.25 ms; no buffer of 16 B per
+//     vertex and frame parity either).
+// Both give the same bits, so the choice never shows in the image.
+struct ClipXYW { float x, y, w; };
+__device__ __forceinline__ ClipXYW corner_clip(const DrawItem& d, FrameConstRef fc, const float (&p)[3]) {
+    const float4 c = clip_position(d, fc.pv, p[0], p[1], p[2]);
+    return ClipXYW{c.x, c.y, c.w};
+}
+
 __device__ __forceinline__ void frag_indices(const DrawItem& d, uint32_t id, FragFetch& f, bool& ok) {
     // straight-line: an index that would leave its buffer is clamped and reported, not branched on
     uint32_t t = id - d.tri_base;
@@ -1574,16 +1595,15 @@ __device__ __forceinline__ void frag_indices(const DrawItem& d, uint32_t id, Fra
     f.i0 = ix[0]; f.i1 = ix[1]; f.i2 = ix[2];
 }
 
-template <bool kTextures>
+template <bool kTextures, bool kStored>
 __device__ __forceinline__ void frag_fetch(const DrawItem& d, FrameConstRef fc, const float4* __restrict__ clip, FragFetch& f,
                                            bool ok, FrameCounters* counters) {
     const uint32_t last_v = max(d.n_verts, 1u) - 1u;
     ok = ok && max(f.i0, max(f.i1, f.i2)) <= last_v && d.n_verts != 0u && d.vert_base + d.n_verts <= fc.n_verts;
     const uint32_t i0 = min(f.i0, last_v), i1 = min(f.i1, last_v), i2 = min(f.i2, last_v);
     guard(ok, counters, kGuardShade);
-    const uint32_t last_c = max(fc.n_verts, 1u) - 1u;
     const bool want_uv = kTextures && d.texture != RND_NONE;
-    if (world_from_clip(d, fc)) {
+    if (kStored && world_from_clip(d, fc)) {           // (every branch here is uniform over the wave)
         gptr_f32 vf = (gptr_f32)d.verts;
         gptr_f32 a = vf + 8ull * i0 + 3, b = vf + 8ull * i1 + 3, c = vf + 8ull * i2 + 3;
         f.n0[0] = a[0]; f.n0[1] = a[1]; f.n0[2] = a[2];
@@ -1591,33 +1611,48 @@ __device__ __forceinline__ void frag_fetch(const DrawItem& d, FrameConstRef fc, 
         f.n2[0] = c[0]; f.n2[1] = c[1]; f.n2[2] = c[2];
         if (want_uv) { f.u0 = a[3]; f.v0 = a[4]; f.u1 = b[3]; f.v1 = b[4]; f.u2 = c[3]; f.v2 = c[4]; }
     } else {
+        // a corner is its 32-byte source vertex: position + normal.x in the first 16 bytes, normal.yz (+ uv) in the
+        // second half of the same 32-byte sector
         gptr_f32x4 vp = (gptr_f32x4)d.verts;
-        const f32x4 a0 = vp[2ull * i0], a1 = vp[2ull * i0 + 1];
-        const f32x4 b0 = vp[2ull * i1], b1 = vp[2ull * i1 + 1];
-        const f32x4 c0 = vp[2ull * i2], c1 = vp[2ull * i2 + 1];
-        f.p0[0] = a0.x; f.p0[1] = a0.y; f.p0[2] = a0.z; f.n0[0] = a0.w; f.n0[1] = a1.x; f.n0[2] = a1.y;
-        f.p1[0] = b0.x; f.p1[1] = b0.y; f.p1[2] = b0.z; f.n1[0] = b0.w; f.n1[1] = b1.x; f.n1[2] = b1.y;
-        f.p2[0] = c0.x; f.p2[1] = c0.y; f.p2[2] = c0.z; f.n2[0] = c0.w; f.n2[1] = c1.x; f.n2[2] = c1.y;
-        f.u0 = a1.z; f.v0 = a1.w; f.u1 = b1.z; f.v1 = b1.w; f.u2 = c1.z; f.v2 = c1.w;
+        const f32x4 a0 = vp[2ull * i0], b0 = vp[2ull * i1], c0 = vp[2ull * i2];
+        f.p0[0] = a0.x; f.p0[1] = a0.y; f.p0[2] = a0.z; f.n0[0] = a0.w;
+        f.p1[0] = b0.x; f.p1[1] = b0.y; f.p1[2] = b0.z; f.n1[0] = b0.w;
+        f.p2[0] = c0.x; f.p2[1] = c0.y; f.p2[2] = c0.z; f.n2[0] = c0.w;
+        if (want_uv) {
+            const f32x4 a1 = vp[2ull * i0 + 1], b1 = vp[2ull * i1 + 1], c1 = vp[2ull * i2 + 1];
+            f.n0[1] = a1.x; f.n0[2] = a1.y; f.n1[1] = b1.x; f.n1[2] = b1.y; f.n2[1] = c1.x; f.n2[2] = c1.y;
+            f.u0 = a1.z; f.v0 = a1.w; f.u1 = b1.z; f.v1 = b1.w; f.u2 = c1.z; f.v2 = c1.w;
+        } else {
+            gptr_f32x2 hp = (gptr_f32x2)d.verts;
+            const f32x2 a1 = hp[4ull * i0 + 2], b1 = hp[4ull * i1 + 2], c1 = hp[4ull * i2 + 2];
+            f.n0[1] = a1.x; f.n0[2] = a1.y; f.n1[1] = b1.x; f.n1[2] = b1.y; f.n2[1] = c1.x; f.n2[2] = c1.y;
+        }
     }
-    // whole 16-byte loads: z is not used here, and left alone the compiler narrows each load to an 8-byte
-    // and a 4-byte one — for divergent gathers the cost is per (lane, instruction), not per byte
-    gptr_f32x4 cp = (gptr_f32x4)clip;
-    f.q0 = cp[min(d.vert_base + i0, last_c)]; f.q1 = cp[min(d.vert_base + i1, last_c)]; f.q2 = cp[min(d.vert_base + i2, last_c)];
+    if constexpr (kStored) {
+        // whole 16-byte loads: z is not used here, and left alone the compiler narrows each load to an 8-byte
+        // and a 4-byte one — for divergent gathers the cost is per (lane, instruction), not per byte
+        const uint32_t last_c = max(fc.n_verts, 1u) - 1u;
+        gptr_f32x4 cp = (gptr_f32x4)clip;
+        f.q0 = cp[min(d.vert_base + i0, last_c)]; f.q1 = cp[min(d.vert_base + i1, last_c)]; f.q2 = cp[min(d.vert_base + i2, last_c)];
+    }
 }
 
-template <bool kTextures>
-__device__ __forceinline__ void frag_finish(const DrawItem& d, FrameConstRef fc, const TextureDesc* __restrict__ textures,
-                                            const float* lut, uint32_t i, uint32_t j, FragFetch& f, PixelInputs& o) {
+template <bool kTextures, bool kStored>
+__device__ __forceinline__ void frag_finish(const DrawItem& d, FrameConstRef fc, const float4* __restrict__ clip,
+                                            const TextureDesc* __restrict__ textures, const float* lut, uint32_t i, uint32_t j, FragFetch& f, PixelInputs& o) {
 #if RND_FAST_SHADE
     // products and sums of the interpolation and of the two transforms may contract to FMAs here, as in the light loop:
     // colour parity is a tolerance (the coverage / depth arithmetic of the raster kernels never contracts)
 #pragma clang fp contract(fast)
 #endif
-    asm volatile("" : "+v"(f.q0), "+v"(f.q1), "+v"(f.q2));
-    const float4 c0 = make_float4(f.q0.x, f.q0.y, f.q0.z, f.q0.w), c1 = make_float4(f.q1.x, f.q1.y, f.q1.z, f.q1.w),
-                 c2 = make_float4(f.q2.x, f.q2.y, f.q2.z, f.q2.w);
     const bool from_clip = world_from_clip(d, fc);
+    ClipXYW c0, c1, c2;
+    if constexpr (kStored) {
+        asm volatile("" : "+v"(f.q0), "+v"(f.q1), "+v"(f.q2));
+        c0 = ClipXYW{f.q0.x, f.q0.y, f.q0.w}; c1 = ClipXYW{f.q1.x, f.q1.y, f.q1.w}; c2 = ClipXYW{f.q2.x, f.q2.y, f.q2.w};
+    } else {
+        c0 = corner_clip(d, fc, f.p0); c1 = corner_clip(d, fc, f.p1); c2 = corner_clip(d, fc, f.p2);
+    }
     const bool want_uv = kTextures && d.texture != RND_NONE;
     const float u0 = f.u0, v0 = f.v0, u1 = f.u1, v1 = f.v1, u2 = f.u2, v2 = f.v2;
     // perspective-correct barycentrics: 2D homogeneous edge functions of (x, y, w) at the pixel centre
@@ -1724,15 +1759,15 @@ __device__ __forceinline__ void complete_inputs(PixelInputs& o, FrameConstRef fc
 }
 
 // the three stages in a row, for one pixel
-template <bool kTextures>
+template <bool kTextures, bool kStored>
 __device__ __forceinline__ void prepare_pixel(const DrawItem& d, FrameConstRef fc, const float4* __restrict__ clip,
                                               const TextureDesc* __restrict__ textures, const float* lut, uint32_t id, uint32_t i,
                                               uint32_t j, PixelInputs& o, FrameCounters* counters) {
     FragFetch f;
     bool ok;
     frag_indices(d, id, f, ok);
-    frag_fetch<kTextures>(d, fc, clip, f, ok, counters);
-    frag_finish<kTextures>(d, fc, textures, lut, i, j, f, o);
+    frag_fetch<kTextures, kStored>(d, fc, clip, f, ok, counters);
+    frag_finish<kTextures, kStored>(d, fc, clip, textures, lut, i, j, f, o);
 }
 
 // compute_light_occlusion (render_mesh.wgsl:184-252): cascade by view depth, biased position
@@ -1886,7 +1921,6 @@ __device__ __forceinline__ void add_light(const GpuLight& L, PixelInputs& p, con
 // Two fragments per lane through the packed f32 pipe (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32):
 // the same Blinn-Phong terms as add_light with products and sums contracted to FMAs and the
 // colour factors regrouped ((b*c) * ((diff + spec) * intensity)); colour parity is a tolerance.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct PixelPair {
     f32x2 fx, fy, fz, Nx, Ny, Nz, Vx, Vy, Vz, br, bg, bb, cr, cg, cb;
     f32x2 NV;               // N . V
@@ -1978,7 +2012,7 @@ __device__ __forceinline__ GpuLight load_light_uniform(const GpuLight* lights, u
 // winning triangle is shaded at the pixel centre, exactly as the reference's per-pixel fragment stage,
 // and re-used while consecutive samples hold the same triangle — each sample keeps the f16 colour,
 // and the pixel gets their mean (the resolve attachment, visual_server.rs:1134-1153).
-template <int PPT, bool kShadows, int kSamples>
+template <int PPT, bool kShadows, int kSamples, bool kStored>
 __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? (kSamples > 1 ? 4 : 7) : 1) void k_shade(FrameBuffers fb) {
     FrameConstRef fc = frame_const_ref(fb.frame_const);
     static_assert(kSamples == 1 || PPT == 2, "the MSAA variant shades one pixel per lane, two of its samples at a time");
@@ -2101,10 +2135,10 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? (kSamples > 1 ? 4 : 
 #pragma unroll
                     for (uint32_t k = 0; k < PPT; ++k) frag_indices(d, covered[k] ? id[k] : d.tri_base, f[k], ok[k]);
 #pragma unroll
-                    for (uint32_t k = 0; k < PPT; ++k) frag_fetch<kShadows>(d, fc, fb.clip, f[k], ok[k] || !covered[k], fb.counters);
+                    for (uint32_t k = 0; k < PPT; ++k) frag_fetch<kShadows, kStored>(d, fc, fb.clip, f[k], ok[k] || !covered[k], fb.counters);
 #pragma unroll
                     for (uint32_t k = 0; k < PPT; ++k)
-                        if (covered[k]) frag_finish<kShadows>(d, fc, fb.textures, s_lut, pi[k], pj[k], f[k], fresh[k]);
+                        if (covered[k]) frag_finish<kShadows, kStored>(d, fc, fb.clip, fb.textures, s_lut, pi[k], pj[k], f[k], fresh[k]);
                 }
             }
         } else staged = true;        // nothing covered
@@ -2122,7 +2156,7 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? (kSamples > 1 ? 4 : 
             if (__ballot(covered[k] && it[k] != lead) == 0ull) {
                 // every covered pixel of the wave belongs to one draw item
                 const DrawItem d = load_item_uniform(fb.items, lead_s);
-                if (covered[k]) prepare_pixel<kShadows>(d, fc, fb.clip, fb.textures, s_lut, id[k], pi[k], pj[k], fresh[k], fb.counters);
+                if (covered[k]) prepare_pixel<kShadows, kStored>(d, fc, fb.clip, fb.textures, s_lut, id[k], pi[k], pj[k], fresh[k], fb.counters);
             } else if (covered[k]) {
                 // waterfall: one pass per distinct draw item among the wave's pixels
                 for (unsigned long long pending = __ballot(true); pending;) {
@@ -2131,7 +2165,7 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? (kSamples > 1 ? 4 : 
                     pending &= ~__ballot(mine);
                     if (mine) {
                         const DrawItem d = load_item_uniform(fb.items, cur_s);
-                        prepare_pixel<kShadows>(d, fc, fb.clip, fb.textures, s_lut, id[k], pi[k], pj[k], fresh[k], fb.counters);
+                        prepare_pixel<kShadows, kStored>(d, fc, fb.clip, fb.textures, s_lut, id[k], pi[k], pj[k], fresh[k], fb.counters);
                     }
                 }
             }
@@ -2609,17 +2643,17 @@ void launch_shade(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stre
     const bool plain = fc.n_samples != 4 && ppt == 2 && !sh;
     const unsigned pad = lds_env >= 0 ? (unsigned)lds_env : (plain ? 2048u : 0u);
     if (fc.n_samples == 4) {
-        if (sh) hipLaunchKernelGGL((k_shade<2, true, 4>), dim3(fb.n_owned * 4), dim3(256), pad, stream, fb);
-        else hipLaunchKernelGGL((k_shade<2, false, 4>), dim3(fb.n_owned * 4), dim3(256), pad, stream, fb);
+        if (sh) hipLaunchKernelGGL((fb.clip ? k_shade<2, true, 4, true> : k_shade<2, true, 4, false>), dim3(fb.n_owned * 4), dim3(256), pad, stream, fb);
+        else hipLaunchKernelGGL((fb.clip ? k_shade<2, false, 4, true> : k_shade<2, false, 4, false>), dim3(fb.n_owned * 4), dim3(256), pad, stream, fb);
     } else if (ppt == 4) {
-        if (sh) hipLaunchKernelGGL((k_shade<4, true, 1>), dim3(fb.n_owned), dim3(256), pad, stream, fb);
-        else hipLaunchKernelGGL((k_shade<4, false, 1>), dim3(fb.n_owned), dim3(256), pad, stream, fb);
+        if (sh) hipLaunchKernelGGL((fb.clip ? k_shade<4, true, 1, true> : k_shade<4, true, 1, false>), dim3(fb.n_owned), dim3(256), pad, stream, fb);
+        else hipLaunchKernelGGL((fb.clip ? k_shade<4, false, 1, true> : k_shade<4, false, 1, false>), dim3(fb.n_owned), dim3(256), pad, stream, fb);
     } else if (ppt == 2) {
-        if (sh) hipLaunchKernelGGL((k_shade<2, true, 1>), dim3(fb.n_owned * 2), dim3(256), pad, stream, fb);
-        else hipLaunchKernelGGL((k_shade<2, false, 1>), dim3(fb.n_owned * 2), dim3(256), pad, stream, fb);
+        if (sh) hipLaunchKernelGGL((fb.clip ? k_shade<2, true, 1, true> : k_shade<2, true, 1, false>), dim3(fb.n_owned * 2), dim3(256), pad, stream, fb);
+        else hipLaunchKernelGGL((fb.clip ? k_shade<2, false, 1, true> : k_shade<2, false, 1, false>), dim3(fb.n_owned * 2), dim3(256), pad, stream, fb);
     } else {
-        if (sh) hipLaunchKernelGGL((k_shade<1, true, 1>), dim3(fb.n_owned * 4), dim3(256), pad, stream, fb);
-        else hipLaunchKernelGGL((k_shade<1, false, 1>), dim3(fb.n_owned * 4), dim3(256), pad, stream, fb);
+        if (sh) hipLaunchKernelGGL((fb.clip ? k_shade<1, true, 1, true> : k_shade<1, true, 1, false>), dim3(fb.n_owned * 4), dim3(256), pad, stream, fb);
+        else hipLaunchKernelGGL((fb.clip ? k_shade<1, false, 1, true> : k_shade<1, false, 1, false>), dim3(fb.n_owned * 4), dim3(256), pad, stream, fb);
     }
 }
 void launch_extract(const uint64_t* vis, const TileRef* order, uint32_t n_owned, const FrameConst& fc, float* depth,

@@ -773,8 +773,17 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     const size_t n_vblocks = ((size_t)fc.n_verts / kVertexBlock + 2) * n_views_max;
     const size_t n_unit_words = std::max<size_t>(2 * (size_t)fc.n_units * n_views_max, 2);
     const size_t n_view_verts = std::max<size_t>((size_t)fc.n_verts * n_views_max, 1);
+    // Whether K1 keeps the clip positions for the shading kernel or that kernel makes them again from the corners' vertices
+    // (kernels.hip, corner_clip: the same bits either way).  Storing costs K1 16 of its 44 bytes per vertex (1.45 us per
+    // million vertices) and two buffers of 16 B per vertex; re-deriving costs the shading kernel 36 instructions per
+    // corner (18 us on the 8.3 M pixels of a 4K frame).  Measured: C3 (5 M vertices at 4K) 3370 frames/s storing, 3330
+    // re-deriving; C5 (50 M vertices at 4K) 797 storing, 890 re-deriving.
+    // (RND_STORE_CLIP = 0 / 1 forces one; read per frame, so that one process can test both)
+    const char* const store_clip_env = std::getenv("RND_STORE_CLIP");
+    const bool store_clip = store_clip_env && *store_clip_env ? std::atoi(store_clip_env) != 0
+                                                : (uint64_t)fc.n_verts * 2u <= 3ull * (uint64_t)width_ * height_ * msaa_;
     if (noalloc) {
-        bp.clip = arena.take<float4>(std::max<size_t>(fc.n_verts, 1)); bp.snap = arena.take<SnapVert>(n_view_verts);
+        bp.clip = store_clip ? arena.take<float4>(std::max<size_t>(fc.n_verts, 1)) : nullptr; bp.snap = arena.take<SnapVert>(n_view_verts);
         bp.records = arena.take<SetupRecord>(cap_.records); bp.tilewords = arena.take<uint32_t>(2 * (size_t)cap_.records);
         bp.clip_queue = arena.take<uint32_t>(2 * (size_t)cap_.clip_queue);      // triangle ids, then their views
         bp.chunk_count = arena.take<uint32_t>(n_unit_words);
@@ -788,7 +797,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         bp.counters = arena.take<FrameCounters>(n_counter_sets);
         bp.vis = arena.take<uint64_t>(n_tiles * kTilePixels * msaa_);
     } else {
-        d_clip_[p].ensure(std::max<size_t>(fc.n_verts, 1));        // (the main pass's only: shading reads it)
+        if (store_clip) d_clip_[p].ensure(std::max<size_t>(fc.n_verts, 1));        // (the main pass's only: shading reads it)
         d_snap_.ensure(n_view_verts);
         d_records_.ensure(cap_.records); d_tilewords_.ensure(2 * (size_t)cap_.records);
         d_clip_queue_.ensure(2 * (size_t)cap_.clip_queue);
@@ -802,7 +811,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         if (world_ > 1) d_tiles_.ensure(std::max<size_t>((size_t)n_owned_ * kTilePixels * 4, 4));
         if (want_packed_) d_packed_.ensure((size_t)width_ * height_);
         if (want_hdr) d_hdr_.ensure((size_t)width_ * height_ * 3);
-        bp.clip = d_clip_[p].ptr; bp.snap = d_snap_.ptr; bp.records = d_records_.ptr; bp.tilewords = d_tilewords_.ptr; bp.clip_queue = d_clip_queue_.ptr;
+        bp.clip = store_clip ? d_clip_[p].ptr : nullptr; bp.snap = d_snap_.ptr; bp.records = d_records_.ptr; bp.tilewords = d_tilewords_.ptr; bp.clip_queue = d_clip_queue_.ptr;
         bp.chunk_count = d_chunk_count_.ptr; bp.active_units = d_active_units_.ptr; bp.vblock_needed = d_vblock_needed_.ptr; bp.entries = d_entries_.ptr;
         bp.wide_list = d_wide_list_.ptr; bp.tile_slices = d_tile_slices_.ptr; bp.raster_extra = d_raster_extra_.ptr;
         bp.tile_count = d_tile_count_.ptr; bp.tile_offset = d_tile_offset_.ptr; bp.tile_cursor = d_tile_cursor_.ptr;

@@ -22,6 +22,14 @@ from tests.test_gpu_parity import assert_parity, render_pair, shadow_scene, soup
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["clip-stored", "clip-rederived"])
+def clip_source(request, monkeypatch):
+    """Every test here runs twice: with K1 keeping the clip positions for the shading kernel and with that kernel
+    making them again from the corners' vertices (kernels.hip, corner_clip) — the library picks one per frame from
+    the frame's vertices per pixel, and the image must not tell which."""
+    monkeypatch.setenv("RND_STORE_CLIP", "1" if request.param == "clip-stored" else "0")
+
+
 def both(w, h):
     return VisualServer(w, h, device=0), oracle_server(w, h)
 

@@ -18,6 +18,14 @@ from tests.helpers import make_vertices, oracle_server
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["clip-stored", "clip-rederived"])
+def clip_source(request, monkeypatch):
+    """Every test here runs twice: with K1 keeping the clip positions for the shading kernel and with that kernel
+    making them again from the corners' vertices (kernels.hip, corner_clip) — the library picks one per frame from
+    the frame's vertices per pixel, and the image must not tell which."""
+    monkeypatch.setenv("RND_STORE_CLIP", "1" if request.param == "clip-stored" else "0")
+
+
 def render_pair(scene: SceneDesc, tone=1, materials=None):
     out = []
     for make in (lambda: VisualServer(scene.width, scene.height, device=0), lambda: oracle_server(scene.width, scene.height)):
