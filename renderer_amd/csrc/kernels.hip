@@ -2021,6 +2021,17 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? (kSamples > 1 ? 4 : 
     __shared__ uint32_t s_bases[kLdsItems + 1];
     __shared__ float s_lut[kShadows ? 512 : 1];     // texel decode table (see FetchSrgb8), full variant only
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const TileRef ref = fb.launch_order[blockIdx.x % fb.n_owned];
+    const uint32_t part = (blockIdx.x / fb.n_owned) * (256u * kPix);    // first tile-local pixel of this workgroup
+    const uint32_t tile_x0 = (ref.tile % fc.tiles_x) * kTile, tile_y0 = (ref.tile / fc.tiles_x) * kTile;
+    const unsigned long long* vis0 = reinterpret_cast<const unsigned long long*>(fb.vis) + (size_t)ref.tile * kTilePixels;
+    // The visibility words of the lane's pixels (of its first two samples under MSAA) are requested before anything else:
+    // the first of the fragment phase's dependent round trips then runs beside the workgroup's set-up (tables to LDS,
+    // counters, barrier) instead of after it.
+    unsigned long long key_first[PPT];
+#pragma unroll
+    for (uint32_t k = 0; k < PPT; ++k)
+        key_first[k] = (vis0 + (size_t)(kSamples > 1 ? k : 0u) * fb.vis_stride)[part + wave * (64u * kPix) + (kSamples > 1 ? 0u : k * 64u) + lane];
     if constexpr (kShadows) { s_lut[tid] = fb.srgb_lut[tid]; s_lut[256u + tid] = fb.srgb_lut[256u + tid]; }
     __shared__ ShadowSet s_sets[kShadows ? kLdsShadowSets : 1];      // the first cascade sets (matrices, layer pointers), full variant only
     if constexpr (kShadows) {
@@ -2038,10 +2049,6 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? (kSamples > 1 ? 4 : 
         uint32_t* dst = reinterpret_cast<uint32_t*>(s_lights);
         for (uint32_t k = tid; k < n_words; k += 256u) dst[k] = src[k];
     }
-    const TileRef ref = fb.launch_order[blockIdx.x % fb.n_owned];
-    const uint32_t part = (blockIdx.x / fb.n_owned) * (256u * kPix);    // first tile-local pixel of this workgroup
-    const uint32_t tile_x0 = (ref.tile % fc.tiles_x) * kTile, tile_y0 = (ref.tile / fc.tiles_x) * kTile;
-    const unsigned long long* vis0 = reinterpret_cast<const unsigned long long*>(fb.vis) + (size_t)ref.tile * kTilePixels;
     // A frame whose geometry phase overflowed an internal stream (records, clip queue, bin entries: triangles were
     // dropped) is not presented: nothing is written, the image keeps the previous frame.  The host learns of it
     // from the report (no synchronization) and has grown the streams by the next frame; rnd_finish re-runs it.
@@ -2087,7 +2094,7 @@ __global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? (kSamples > 1 ? 4 : 
         const unsigned long long* vis = vis0 + (size_t)(kSamples > 1 ? (uint32_t)smp + k : 0u) * fb.vis_stride;
         uint32_t local = part + wave * (64u * kPix) + (kSamples > 1 ? 0u : k * 64u) + lane;      // a wave holds 2*kPix consecutive rows
         pi[k] = tile_x0 + (local & (kTile - 1)); pj[k] = tile_y0 + (local / kTile);
-        key[k] = vis[local];
+        key[k] = smp == 0 ? key_first[k] : vis[local];
     }
 #pragma unroll
     for (uint32_t k = 0; k < PPT; ++k) {
