@@ -1946,10 +1946,34 @@ template <bool kShadows>
 __device__ __forceinline__ void add_light_pair(const GpuLight& L, PixelPair& p, const ShadowSet* __restrict__ sets,
                                                const ShadowSet* lds_sets, FrameConstRef fc) {
 #pragma clang fp contract(fast)
-    f32x2 ox, oy, oz, inv_d, dist, inten;
+    // The part both kinds of light share, instantiated once per kind.  Cosines of unit vectors are clamped to [0, 1]
+    // instead of max(., 0): the same value up to the last bit of a cosine that rounds above one, and the clamp rides on
+    // the multiply that produces it (an output modifier) where the maximum was an instruction of its own.  A point
+    // light's diffuse term is such a cosine; a directional light's is not (its direction is not normalized, as in the
+    // shader), so that one keeps the maximum.
+    // (the light's fields come in by value: a capture of L by reference kept the whole struct in memory in the full variant)
+    const float cr = L.color[0], cg = L.color[1], cb = L.color[2];
+    auto finish = [&p, cr, cg, cb](auto is_point, f32x2 ox, f32x2 oy, f32x2 oz, f32x2 inv_d, f32x2 dist, f32x2 inten) {
+        f32x2 No = p.Nx * ox + p.Ny * oy + p.Nz * oz;
+        f32x2 diff;
+        if constexpr (decltype(is_point)::value) {
+            const f32x2 t = -(No * inv_d);
+            diff = (f32x2){fminf(fmaxf(t.x, 0.0f), 1.0f), fminf(fmaxf(t.y, 0.0f), 1.0f)};
+        } else diff = max0(-No);
+        f32x2 hx = p.Vx * dist - ox, hy = p.Vy * dist - oy, hz = p.Vz * dist - oz;
+        f32x2 inv_h = rsq2(hx * hx + hy * hy + hz * hz);
+        const f32x2 st = (p.NV * dist - No) * inv_h;
+        f32x2 sp = (f32x2){fminf(fmaxf(st.x, 0.0f), 1.0f), fminf(fmaxf(st.y, 0.0f), 1.0f)};
+        f32x2 s2 = sp * sp, s4 = s2 * s2;
+        // the lights' sum is kept apart from the base colour and multiplied in once after the loop
+        // (base * sum(c_l * w_l) for sum(base * c_l * w_l): three packed multiplies less per light)
+        f32x2 w = (s4 * s4 + diff) * inten;
+        p.ar += splat2(cr) * w;
+        p.ag += splat2(cg) * w;
+        p.ab += splat2(cb) * w;
+    };
     if (L.kind == RND_LIGHT_DIRECTIONAL) {
-        ox = splat2(L.dir[0]); oy = splat2(L.dir[1]); oz = splat2(L.dir[2]);
-        inv_d = dist = splat2(1.0f);
+        const f32x2 ox = splat2(L.dir[0]), oy = splat2(L.dir[1]), oz = splat2(L.dir[2]);
         float i0 = L.color[3], i1 = L.color[3];
         if constexpr (kShadows) {
             if ((uint32_t)L.shadow_index >= kLdsShadowSets) {       // (uniform over the wave) none, or beyond the LDS copy: one by one
@@ -1966,28 +1990,16 @@ __device__ __forceinline__ void add_light_pair(const GpuLight& L, PixelPair& p, 
                 i1 = L.color[3] * (1.0f - shadow_taps_count(q1, t1, in1));
             }
         }
-        inten = (f32x2){i0, i1};
+        finish(std::false_type{}, ox, oy, oz, splat2(1.0f), splat2(1.0f), (f32x2){i0, i1});
     } else {
-        ox = p.fx - splat2(L.pos[0]); oy = p.fy - splat2(L.pos[1]); oz = p.fz - splat2(L.pos[2]);
+        f32x2 ox = p.fx - splat2(L.pos[0]), oy = p.fy - splat2(L.pos[1]), oz = p.fz - splat2(L.pos[2]);
         f32x2 d2 = ox * ox + oy * oy + oz * oz;
-        inv_d = rsq2(d2);
-        dist = d2 * inv_d;
+        f32x2 inv_d = rsq2(d2);
+        f32x2 dist = d2 * inv_d;
         f32x2 lin = splat2(1.0f) - dist * splat2(L.inv_radius);
         lin = (f32x2){fminf(fmaxf(lin.x, 0.0f), 1.0f), fminf(fmaxf(lin.y, 0.0f), 1.0f)};
-        inten = ((lin * lin) * (splat2(3.0f) - splat2(2.0f) * lin)) * splat2(L.color[3]);
+        finish(std::true_type{}, ox, oy, oz, inv_d, dist, ((lin * lin) * (splat2(3.0f) - splat2(2.0f) * lin)) * splat2(L.color[3]));
     }
-    f32x2 No = p.Nx * ox + p.Ny * oy + p.Nz * oz;
-    f32x2 diff = max0(-(No * inv_d));
-    f32x2 hx = p.Vx * dist - ox, hy = p.Vy * dist - oy, hz = p.Vz * dist - oz;
-    f32x2 inv_h = rsq2(hx * hx + hy * hy + hz * hz);
-    f32x2 sp = max0((p.NV * dist - No) * inv_h);
-    f32x2 s2 = sp * sp, s4 = s2 * s2;
-    // the lights' sum is kept apart from the base colour and multiplied in once after the loop
-    // (base * sum(c_l * w_l) for sum(base * c_l * w_l): three packed multiplies less per light)
-    f32x2 w = (s4 * s4 + diff) * inten;
-    p.ar += splat2(L.color[0]) * w;
-    p.ag += splat2(L.color[1]) * w;
-    p.ab += splat2(L.color[2]) * w;
 }
 
 // one light through scalar loads (its index is wave-uniform)
