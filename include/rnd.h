@@ -230,8 +230,8 @@ int rnd_finish(rnd_ctx* ctx);
  * pixels as rnd_render, but
  *  - the image goes to the caller's device buffer `out_rgba8_dev` (row-major width*height*4 bytes; on a tile
  *    partition the tile-major n_owned_tiles*tile_px*tile_px*4 bytes of rnd_tiles_device_ptr), and
- *  - every intermediate stream of the frame (table block, clip positions, snapped vertices, visibility words,
- *    setup records, bin entries, queues, counters) lives in one static 128 MiB device array inside the library
+ *  - every intermediate stream of the frame (table block, clip positions where the frame keeps them, snapped vertices,
+ *    visibility words, setup records, bin entries, queues, counters) lives in one static 128 MiB device array inside the library
  *    instead of hipMalloc'ed buffers; its per-device address is looked up once in rnd_create.
  * The call allocates nothing on the device or in pinned memory and frees nothing.  Limits: the frame's streams
  * must fit the array (about 1 M triangles at 1920x1080; RND_ERR_INVALID with the sizes otherwise, before

@@ -28,7 +28,7 @@ struct FrameBuffers {
     uint2* active_units;            // (item, chunk) of the work units that survived k_cull
     uint32_t* vblock_needed;        // per kVertexBlock block of the frame's vertex slots: used by a surviving unit
     // geometry stage
-    float4* clip;                   // n_verts clip positions
+    float4* clip;                   // n_verts clip positions K1 keeps for k_shade, or null: k_shade makes them again (corner_clip)
     SnapVert* snap;                 // n_verts snapped positions + clip verdicts (K1 -> K2a)
     uint32_t* wide_list;            // record slots of the wide records of this pass
     uint32_t* tile_slices;          // per tile: raster workgroups that share it (k_scan_tiles -> k_raster)

@@ -248,7 +248,7 @@ private:
     // device state
     // Consecutive frames overlap: the geometry phase of frame N+1 (clear .. raster, on geo_stream_) runs
     // beside the shading of frame N (on stream_).  What shading reads from the geometry phase exists twice
-    // (index = frame parity): per-frame tables, clip positions, visibility buffer, counters.
+    // (index = frame parity): per-frame tables, clip positions (frames that keep them), visibility buffer, counters.
     hipStream_t geo_stream_ = nullptr;
     hipEvent_t geo_done_[2] = {}, shade_done_[2] = {};
     uint32_t parity_ = 0;              // buffers of the last enqueued frame
