@@ -2025,7 +2025,11 @@ __device__ __forceinline__ GpuLight load_light_uniform(const GpuLight* lights, u
 // and re-used while consecutive samples hold the same triangle — each sample keeps the f16 colour,
 // and the pixel gets their mean (the resolve attachment, visual_server.rs:1134-1153).
 template <int PPT, bool kShadows, int kSamples, bool kStored>
-__global__ __launch_bounds__(256, (PPT == 2 && !kShadows) ? (kSamples > 1 ? 4 : 7) : 1) void k_shade(FrameBuffers fb) {
+// (waves per SIMD the variants are compiled for: the plain one 7, the full one 5 — 95 VGPRs without a spill where the
+// compiler left alone took 101 and with them a fifth wave: C3 + sun shade 0.268 -> 0.241 ms —, plain MSAA 5 (seven
+// spilled dwords at 96 VGPRs against 102 at four waves: C3 MSAA x4 shade 0.72 -> 0.68 ms); the full MSAA variant spills
+// 29 at 4 and keeps its 3)
+__global__ __launch_bounds__(256, PPT != 2 ? 1 : (kShadows ? (kSamples > 1 ? 1 : 5) : (kSamples > 1 ? 5 : 7))) void k_shade(FrameBuffers fb) {
     FrameConstRef fc = frame_const_ref(fb.frame_const);
     static_assert(kSamples == 1 || PPT == 2, "the MSAA variant shades one pixel per lane, two of its samples at a time");
     constexpr uint32_t kPix = kSamples > 1 ? 1u : (uint32_t)PPT;        // pixels per lane
