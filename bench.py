@@ -30,6 +30,12 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
 N_SIMDS, VALU_CLOCK_HZ = 256 * 4, 2.4e9      # a wave64 VALU instruction takes a SIMD's 32 lanes for 2 cycles (MI355X_MICROARCH.md)
 TIMED_FRAMES = 16          # frames with events around every kernel, after the throughput loop (outside `elapsed`)
+SETTLE_FRAMES = 200        # untimed frames before them when the run was short: the VALU-bound kernels take ~200 frames
+                           # (60 ms) of load to reach the duration they keep (k_shade at C3: 0.179 ms after 25 frames,
+                           # 0.167 after 65, 0.163 after 205 and after 805; the bandwidth-bound k_transform does not
+                           # move), and the per-kernel table and the roofline entries describe the kernels, not the
+                           # GPU's clock ramp.  `value` / `ms_per_step` are not touched by this: they are what the
+                           # K timed steps after the W warm-up steps took.
 
 WORKLOADS = {
     # name -> (scene builder name, description)
@@ -288,6 +294,10 @@ def main():
 
     # per-kernel durations: TIMED_FRAMES more frames of the same workload, each with HIP events around every
     # kernel (on the streams the kernels are launched on) and without the overlap with its neighbours
+    settle = max(0, SETTLE_FRAMES - args.warmup - args.steps)
+    for _ in range(settle):
+        step()
+    fence()
     vs.timing_stats(reset=True)
     vs.time_frames(TIMED_FRAMES)
     for _ in range(TIMED_FRAMES):
@@ -351,7 +361,7 @@ def main():
             "roofline_raster": roofline_of("raster"),
             "kernels": kernels,
             "dropped_frames": driver.dropped,
-            "gpu_frame_ms": round(mean["frame_ms"], 4), "timed_frames": n_frames,
+            "gpu_frame_ms": round(mean["frame_ms"], 4), "timed_frames": n_frames, "settle_frames_before_kernel_timing": settle,
             "frame_stats": stats,
         }
         if world == 1 and not args.no_cpu_baseline:
