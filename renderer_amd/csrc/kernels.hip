@@ -109,6 +109,16 @@ typedef const __attribute__((address_space(1))) f32x4* gptr_f32x4;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) f32x2* gptr_f32x2;
 
+// A load at a wave-uniform base + a 32-bit byte offset per lane: one scalar base and one vector offset in the
+// instruction, where `base[index]` costs a 64-bit shift and a 64-bit add per lane (4-cycle instructions each).  The
+// caller guarantees that the offset fits 32 bits.
+template <class T>
+__device__ __forceinline__ T load_at(const void* base_uniform, uint32_t byte_offset) {
+    typedef const __attribute__((address_space(1))) char* gptr_char;
+    typedef const __attribute__((address_space(1))) T* gptr_t;
+    return *(gptr_t)((gptr_char)base_uniform + byte_offset);
+}
+
 // Waterfall helper: picks the value of `v` held by the first lane of `pending` as a scalar.
 // Two things make the obvious `cur = readfirstlane(v); if (cur == v) {...}` loop unsafe: the
 // optimizer may hoist the (loop-invariant) readfirstlane out of the loop, and inside the
@@ -1591,8 +1601,10 @@ __device__ __forceinline__ void frag_indices(const DrawItem& d, uint32_t id, Fra
     uint32_t t = id - d.tri_base;
     ok = t < d.n_tris;
     t = ok ? t : 0u;
-    gptr_u32 ix = (gptr_u32)d.indices + 3ull * t;
-    f.i0 = ix[0]; f.i1 = ix[1]; f.i2 = ix[2];
+    // (12 bytes per triangle: 32-bit offsets reach 357 M triangles of one item; the host refuses larger submeshes)
+    typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+    const u32x3 ix = load_at<u32x3>(d.indices, t * 12u);
+    f.i0 = ix.x; f.i1 = ix.y; f.i2 = ix.z;
 }
 
 template <bool kTextures, bool kStored>
@@ -1604,27 +1616,29 @@ __device__ __forceinline__ void frag_fetch(const DrawItem& d, FrameConstRef fc, 
     guard(ok, counters, kGuardShade);
     const bool want_uv = kTextures && d.texture != RND_NONE;
     if (kStored && world_from_clip(d, fc)) {           // (every branch here is uniform over the wave)
-        gptr_f32 vf = (gptr_f32)d.verts;
-        gptr_f32 a = vf + 8ull * i0 + 3, b = vf + 8ull * i1 + 3, c = vf + 8ull * i2 + 3;
-        f.n0[0] = a[0]; f.n0[1] = a[1]; f.n0[2] = a[2];
-        f.n1[0] = b[0]; f.n1[1] = b[1]; f.n1[2] = b[2];
-        f.n2[0] = c[0]; f.n2[1] = c[1]; f.n2[2] = c[2];
-        if (want_uv) { f.u0 = a[3]; f.v0 = a[4]; f.u1 = b[3]; f.v1 = b[4]; f.u2 = c[3]; f.v2 = c[4]; }
+        // (32 bytes per vertex: 32-bit offsets reach 134 M vertices of one item)
+        typedef float f32x3 __attribute__((ext_vector_type(3)));
+        const f32x3 a = load_at<f32x3>(d.verts, i0 * 32u + 12u), b = load_at<f32x3>(d.verts, i1 * 32u + 12u), c = load_at<f32x3>(d.verts, i2 * 32u + 12u);
+        f.n0[0] = a.x; f.n0[1] = a.y; f.n0[2] = a.z;
+        f.n1[0] = b.x; f.n1[1] = b.y; f.n1[2] = b.z;
+        f.n2[0] = c.x; f.n2[1] = c.y; f.n2[2] = c.z;
+        if (want_uv) {
+            const f32x2 ua = load_at<f32x2>(d.verts, i0 * 32u + 24u), ub = load_at<f32x2>(d.verts, i1 * 32u + 24u), uc = load_at<f32x2>(d.verts, i2 * 32u + 24u);
+            f.u0 = ua.x; f.v0 = ua.y; f.u1 = ub.x; f.v1 = ub.y; f.u2 = uc.x; f.v2 = uc.y;
+        }
     } else {
         // a corner is its 32-byte source vertex: position + normal.x in the first 16 bytes, normal.yz (+ uv) in the
         // second half of the same 32-byte sector
-        gptr_f32x4 vp = (gptr_f32x4)d.verts;
-        const f32x4 a0 = vp[2ull * i0], b0 = vp[2ull * i1], c0 = vp[2ull * i2];
+        const f32x4 a0 = load_at<f32x4>(d.verts, i0 * 32u), b0 = load_at<f32x4>(d.verts, i1 * 32u), c0 = load_at<f32x4>(d.verts, i2 * 32u);
         f.p0[0] = a0.x; f.p0[1] = a0.y; f.p0[2] = a0.z; f.n0[0] = a0.w;
         f.p1[0] = b0.x; f.p1[1] = b0.y; f.p1[2] = b0.z; f.n1[0] = b0.w;
         f.p2[0] = c0.x; f.p2[1] = c0.y; f.p2[2] = c0.z; f.n2[0] = c0.w;
         if (want_uv) {
-            const f32x4 a1 = vp[2ull * i0 + 1], b1 = vp[2ull * i1 + 1], c1 = vp[2ull * i2 + 1];
+            const f32x4 a1 = load_at<f32x4>(d.verts, i0 * 32u + 16u), b1 = load_at<f32x4>(d.verts, i1 * 32u + 16u), c1 = load_at<f32x4>(d.verts, i2 * 32u + 16u);
             f.n0[1] = a1.x; f.n0[2] = a1.y; f.n1[1] = b1.x; f.n1[2] = b1.y; f.n2[1] = c1.x; f.n2[2] = c1.y;
             f.u0 = a1.z; f.v0 = a1.w; f.u1 = b1.z; f.v1 = b1.w; f.u2 = c1.z; f.v2 = c1.w;
         } else {
-            gptr_f32x2 hp = (gptr_f32x2)d.verts;
-            const f32x2 a1 = hp[4ull * i0 + 2], b1 = hp[4ull * i1 + 2], c1 = hp[4ull * i2 + 2];
+            const f32x2 a1 = load_at<f32x2>(d.verts, i0 * 32u + 16u), b1 = load_at<f32x2>(d.verts, i1 * 32u + 16u), c1 = load_at<f32x2>(d.verts, i2 * 32u + 16u);
             f.n0[1] = a1.x; f.n0[2] = a1.y; f.n1[1] = b1.x; f.n1[2] = b1.y; f.n2[1] = c1.x; f.n2[2] = c1.y;
         }
     }
@@ -1632,8 +1646,9 @@ __device__ __forceinline__ void frag_fetch(const DrawItem& d, FrameConstRef fc, 
         // whole 16-byte loads: z is not used here, and left alone the compiler narrows each load to an 8-byte
         // and a 4-byte one — for divergent gathers the cost is per (lane, instruction), not per byte
         const uint32_t last_c = max(fc.n_verts, 1u) - 1u;
-        gptr_f32x4 cp = (gptr_f32x4)clip;
-        f.q0 = cp[min(d.vert_base + i0, last_c)]; f.q1 = cp[min(d.vert_base + i1, last_c)]; f.q2 = cp[min(d.vert_base + i2, last_c)];
+        // (16 bytes per vertex of the frame: the host keeps clip positions only in frames of fewer than 2^28 vertices)
+        f.q0 = load_at<f32x4>(clip, min(d.vert_base + i0, last_c) * 16u); f.q1 = load_at<f32x4>(clip, min(d.vert_base + i1, last_c) * 16u);
+        f.q2 = load_at<f32x4>(clip, min(d.vert_base + i2, last_c) * 16u);
     }
 }
 

@@ -249,6 +249,9 @@ void VisualServer::register_mesh(uint32_t mesh_id, uint32_t n_submeshes, const r
         const rnd_submesh_desc& d = subs[k];
         if ((d.n_vertices && !d.vertices) || (d.n_indices && !d.indices) || d.n_indices % 3)
             throw Error(RND_ERR_INVALID, "bad submesh (null pointer or index count not a multiple of 3)");
+        // (the shading kernel addresses a submesh's vertices and indices by 32-bit byte offsets: 32 B per vertex, 4 B per index)
+        if ((uint64_t)d.n_vertices * 32u > 0xFFFFFFFFull || (uint64_t)d.n_indices * 4u > 0xFFFFFFFFull)
+            throw Error(RND_ERR_INVALID, "submesh exceeds 4 GiB of vertices or indices");
         for (uint32_t i = 0; i < d.n_indices; ++i)
             if (d.indices[i] >= d.n_vertices) throw Error(RND_ERR_INVALID, "vertex index out of range");
     }
@@ -782,8 +785,10 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     const char* const store_clip_env = std::getenv("RND_STORE_CLIP");
     const bool store_clip = store_clip_env && *store_clip_env ? std::atoi(store_clip_env) != 0
                                                 : (uint64_t)fc.n_verts * 2u <= 3ull * (uint64_t)width_ * height_ * msaa_;
+    // (16 B per vertex behind a 32-bit byte offset: a frame of 2^28 vertices or more re-derives whatever was asked for)
+    const bool store_clip_fits = fc.n_verts < (1u << 28);
     if (noalloc) {
-        bp.clip = store_clip ? arena.take<float4>(std::max<size_t>(fc.n_verts, 1)) : nullptr; bp.snap = arena.take<SnapVert>(n_view_verts);
+        bp.clip = store_clip && store_clip_fits ? arena.take<float4>(std::max<size_t>(fc.n_verts, 1)) : nullptr; bp.snap = arena.take<SnapVert>(n_view_verts);
         bp.records = arena.take<SetupRecord>(cap_.records); bp.tilewords = arena.take<uint32_t>(2 * (size_t)cap_.records);
         bp.clip_queue = arena.take<uint32_t>(2 * (size_t)cap_.clip_queue);      // triangle ids, then their views
         bp.chunk_count = arena.take<uint32_t>(n_unit_words);
@@ -797,7 +802,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         bp.counters = arena.take<FrameCounters>(n_counter_sets);
         bp.vis = arena.take<uint64_t>(n_tiles * kTilePixels * msaa_);
     } else {
-        if (store_clip) d_clip_[p].ensure(std::max<size_t>(fc.n_verts, 1));        // (the main pass's only: shading reads it)
+        if (store_clip && store_clip_fits) d_clip_[p].ensure(std::max<size_t>(fc.n_verts, 1));        // (the main pass's only: shading reads it)
         d_snap_.ensure(n_view_verts);
         d_records_.ensure(cap_.records); d_tilewords_.ensure(2 * (size_t)cap_.records);
         d_clip_queue_.ensure(2 * (size_t)cap_.clip_queue);
@@ -811,7 +816,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         if (world_ > 1) d_tiles_.ensure(std::max<size_t>((size_t)n_owned_ * kTilePixels * 4, 4));
         if (want_packed_) d_packed_.ensure((size_t)width_ * height_);
         if (want_hdr) d_hdr_.ensure((size_t)width_ * height_ * 3);
-        bp.clip = store_clip ? d_clip_[p].ptr : nullptr; bp.snap = d_snap_.ptr; bp.records = d_records_.ptr; bp.tilewords = d_tilewords_.ptr; bp.clip_queue = d_clip_queue_.ptr;
+        bp.clip = store_clip && store_clip_fits ? d_clip_[p].ptr : nullptr; bp.snap = d_snap_.ptr; bp.records = d_records_.ptr; bp.tilewords = d_tilewords_.ptr; bp.clip_queue = d_clip_queue_.ptr;
         bp.chunk_count = d_chunk_count_.ptr; bp.active_units = d_active_units_.ptr; bp.vblock_needed = d_vblock_needed_.ptr; bp.entries = d_entries_.ptr;
         bp.wide_list = d_wide_list_.ptr; bp.tile_slices = d_tile_slices_.ptr; bp.raster_extra = d_raster_extra_.ptr;
         bp.tile_count = d_tile_count_.ptr; bp.tile_offset = d_tile_offset_.ptr; bp.tile_cursor = d_tile_cursor_.ptr;
