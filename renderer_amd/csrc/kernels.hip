@@ -1118,17 +1118,29 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(FrameBuffers fb, Capacities
     // These loads are issued first so they overlap the scan's.
     const uint32_t n_active = min(fb.counters->n_active, fc.n_units);
     const uint32_t n_wide = min(fb.counters->n_wide, cap.wide_list);
-    uint32_t v = 0;
+    uint32_t v = 0, used = 0;
     for (uint32_t c0 = 0; c0 < n_active; c0 += 8u * 1024u) {
-        uint32_t part[8];
+        uint32_t part[8], slots[8];
 #pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) {          // eight independent loads in flight, not a chain of round trips
+        for (uint32_t k = 0; k < 8; ++k) {          // independent loads in flight, not a chain of round trips
             const uint32_t c = c0 + k * 1024u + tid;
             part[k] = c < n_active ? fb.chunk_count[fc.n_units + c] : 0u;
+            slots[k] = c < n_active ? fb.chunk_count[c] : 0u;
         }
 #pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) v += part[k];
+        for (uint32_t k = 0; k < 8; ++k) { v += part[k]; used |= slots[k]; }
     }
+    // A pass in which no unit wrote a record and the clipper wrote none either (every triangle took k_setup's direct path:
+    // C3, C5, the depth-only passes of such scenes) has no tile counts to scan: k_bin_fill and k_raster look at
+    // n_entries and n_wide alone (both zero then) before anything else, so the offsets, cursors and slice counts of an
+    // earlier frame may stay as they are.  Saves the tile loop's three barriers and two round trips in a kernel that is
+    // one workgroup on the frame's critical chain.
+    __shared__ uint32_t s_any;
+    if (tid == 0) s_any = fb.counters->n_records | n_wide;
+    __syncthreads();
+    if (used) atomicOr(&s_any, 1u);
+    __syncthreads();
+    const bool any_records = s_any != 0u;
     // Tiles go through LDS in batches of 8192 so that global traffic is coalesced (this is a single
     // workgroup on one CU: with a strided pattern its one texture pipe was the whole kernel time).
     // Per batch: coalesced load of count sums into LDS, every thread scans its run of 8 consecutive
@@ -1137,7 +1149,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(FrameBuffers fb, Capacities
     __shared__ uint32_t s_tiles[kBatch + kBatch / 32];          // padded: a run of 8 starts in its own bank group
     __shared__ uint32_t s_batch_total;
     uint32_t carry = 0;
-    for (uint32_t batch = 0; batch < n_tiles; batch += kBatch) {
+    for (uint32_t batch = 0; any_records && batch < n_tiles; batch += kBatch) {
 #pragma unroll
         for (uint32_t k = 0; k < kRun; ++k) {
             const uint32_t local = k * 1024u + tid, i = batch + local;
