@@ -131,7 +131,8 @@ int rnd_set_tone_mapping(rnd_ctx* ctx, uint32_t mode);                       /* 
 
 /* ---- resources (reference: register_mesh :664-695, register_material :697-750) ----- */
 /* Replaces the AssetServer lookup + create_vertex_buffer/create_index_buffer upload.
- * Registering an id twice replaces the mesh. */
+ * Registering an id twice replaces the mesh.  A submesh of more than 4 GiB of vertices (2^27 of them) or of indices
+ * (2^30) is refused with RND_ERR_INVALID: the kernels address a submesh's arrays by 32-bit byte offsets. */
 int rnd_register_mesh(rnd_ctx* ctx, uint32_t mesh_id, uint32_t n_submeshes,
                       const rnd_submesh_desc* submeshes);
 /* reference: update_render_material_data :710-750 packs MaterialUniform :978-985.
