@@ -11,6 +11,14 @@ struct TileRef {
     uint32_t compact;   // position of the tile in this rank's ascending list of owned tiles
 };
 
+// The main pass's shape, by value in the shading kernel's arguments (k_shade: its first loads depend on nothing else).
+struct ShadeDims {
+    uint32_t n_lights, n_items;
+    uint32_t width, height, tiles_x;
+    uint32_t tiles_x_magic;         // floor(2^32 / tiles_x) + 1 (0 when tiles_x is 1): n / tiles_x == umulhi(n, magic) for n < 2^24
+    uint32_t rank, world;           // the sort-first partition (FrameConst::rank, world)
+};
+
 struct FrameBuffers {
     const FrameConst* frame_const;  // this pass's constants, in the per-frame table block
     // per-frame scene tables
@@ -54,6 +62,7 @@ struct FrameBuffers {
     // pixel stage
     const TileRef* launch_order;    // owned tiles in launch order (XCD-aware)
     uint32_t n_owned;
+    ShadeDims dims;
     uint64_t* vis;                  // tile-major (depth bits << 32 | triangle id), 1024 per tile; with MSAA the
                                     // plane of the sample a geometry pass resolves / of sample 0 for shading
     uint64_t vis_stride;            // words between the planes of consecutive samples
@@ -75,6 +84,7 @@ void launch_scan(const FrameBuffers& fb, const FrameConst& fc, const Capacities&
 void launch_bin(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream);
 void launch_raster(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream);
 void launch_shade(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream);
+void shade_profile_dump();     // development aid (-DRND_SHADE_PROFILE builds; a no-op otherwise)
 
 // read-back helpers: tile-major vis -> row-major planes (any pointer may be null)
 void launch_extract(const uint64_t* vis, const TileRef* order, uint32_t n_owned, const FrameConst& fc,

@@ -12,7 +12,9 @@
 // The arithmetic that decides coverage and depth is integer or single IEEE f32 operations in a
 // fixed order (compiled with -ffp-contract=off; f32 divide and sqrt are correctly rounded by
 // hipcc's default), as DESIGN.md "Raster rules" states it, so results are reproducible bit for bit.
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include <hip/hip_fp16.h>
@@ -20,9 +22,6 @@
 
 #include "kernels.h"
 
-#ifndef RND_SCALAR_LIGHTS
-#define RND_SCALAR_LIGHTS 1
-#endif
 #ifndef RND_EARLY_Z
 #define RND_EARLY_Z 0
 #endif
@@ -1945,9 +1944,8 @@ __device__ __forceinline__ void add_light(const GpuLight& L, PixelInputs& p, con
 }
 
 #if RND_FAST_SHADE
-// Two fragments per lane through the packed f32 pipe (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32):
-// the same Blinn-Phong terms as add_light with products and sums contracted to FMAs and the
-// colour factors regrouped ((b*c) * ((diff + spec) * intensity)); colour parity is a tolerance.
+// Two fragments per lane: the same Blinn-Phong terms as add_light with products and sums contracted to FMAs and
+// the colour factors regrouped; colour parity is a tolerance.
 struct PixelPair {
     f32x2 fx, fy, fz, Nx, Ny, Nz, Vx, Vy, Vz, br, bg, bb, cr, cg, cb;
     f32x2 NV;               // N . V
@@ -1957,79 +1955,80 @@ struct PixelPair {
 __device__ __forceinline__ f32x2 splat2(float v) { return (f32x2){v, v}; }
 __device__ __forceinline__ f32x2 rsq2(f32x2 v) { return (f32x2){__builtin_amdgcn_rsqf(v.x), __builtin_amdgcn_rsqf(v.y)}; }
 __device__ __forceinline__ f32x2 max0(f32x2 v) { return (f32x2){fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f)}; }
+__device__ __forceinline__ f32x2 sat2(f32x2 v) { return (f32x2){fminf(fmaxf(v.x, 0.0f), 1.0f), fminf(fmaxf(v.y, 0.0f), 1.0f)}; }
 
-__device__ __forceinline__ float shadow_term(const ShadowSet* __restrict__ sets, const GpuLight& L, FrameConstRef fc,
-                                             float fx, float fy, float fz, float nx, float ny, float nz) {
-    return light_occlusion(sets, L.shadow_index, fc, fx, fy, fz, nx, ny, nz, L.dir[0], L.dir[1], L.dir[2]);
-}
+// A light as the shading kernel keeps it in LDS (32 bytes, two 16-byte reads): position and radius of a point light,
+// or the (unnormalized) direction of a directional one with a negative radius as its mark; the colour already times
+// the intensity.  The light loop reads the current light with all lanes at one address (a broadcast): its fields
+// arrive in VGPRs, and the loop's arithmetic has no SGPR operand — on gfx950 an f32 FMA / multiply / add with an SGPR
+// operand issues at half the rate of one on VGPRs alone (profiles/r02_valu_ops_microbench.txt), and the 32 SGPRs that
+// the scalar-load version held for the current and the next light made the kernel spill SGPRs into VGPR lanes.
+struct ShadeLight { float x, y, z, radius, r, g, b, inv_radius; };
+static_assert(sizeof(ShadeLight) == 32, "ShadeLight is 2 x 16 bytes");
 
 // The lane's lit flags are not looked at here (except to skip shadow look-ups): a lane without a lit fragment
-// computes on zeros and the caller drops its sum.  Straight-line for a point light: beyond the radius the clamped
-// linear term is zero and so is the light's weight, which is what the reference's discard amounts to.
+// computes on whatever it holds and the caller drops its sum.  Straight-line for a point light: beyond the radius the
+// clamped linear term is zero and so is the light's weight, which is what the reference's discard amounts to.
 //   o = frag - light (unnormalized), dist = |o|:   diffuse = max(-(N.o) / dist, 0)
 //   half vector scaled by dist: h' = V * dist - o;  specular base = max((N.h') / |h'|, 0), with N.h' = (N.V) dist - N.o
-// (five packed operations less than normalizing o first; N.V is per fragment, outside the light loop)
-template <bool kShadows>
-__device__ __forceinline__ void add_light_pair(const GpuLight& L, PixelPair& p, const ShadowSet* __restrict__ sets,
-                                               const ShadowSet* lds_sets, FrameConstRef fc) {
+// Cosines of unit vectors are clamped to [0, 1] instead of max(., 0): the same value up to the last bit of a cosine
+// that rounds above one, and the clamp rides on the multiply that produces it.  A point light's diffuse term is such
+// a cosine; a directional light's is not (its direction is not normalized, as in the shader), so that one keeps the
+// maximum.  `inten`: attenuation (point) or 1 - occlusion (directional); the light's colour carries its intensity.
+template <bool kPoint>
+__device__ __forceinline__ void light_pair_finish(PixelPair& p, float cr, float cg, float cb, f32x2 ox, f32x2 oy, f32x2 oz, f32x2 inv_d,
+                                                  f32x2 dist, f32x2 inten) {
 #pragma clang fp contract(fast)
-    // The part both kinds of light share, instantiated once per kind.  Cosines of unit vectors are clamped to [0, 1]
-    // instead of max(., 0): the same value up to the last bit of a cosine that rounds above one, and the clamp rides on
-    // the multiply that produces it (an output modifier) where the maximum was an instruction of its own.  A point
-    // light's diffuse term is such a cosine; a directional light's is not (its direction is not normalized, as in the
-    // shader), so that one keeps the maximum.
-    // (the light's fields come in by value: a capture of L by reference kept the whole struct in memory in the full variant)
-    const float cr = L.color[0], cg = L.color[1], cb = L.color[2];
-    auto finish = [&p, cr, cg, cb](auto is_point, f32x2 ox, f32x2 oy, f32x2 oz, f32x2 inv_d, f32x2 dist, f32x2 inten) {
-        f32x2 No = p.Nx * ox + p.Ny * oy + p.Nz * oz;
-        f32x2 diff;
-        if constexpr (decltype(is_point)::value) {
-            const f32x2 t = -(No * inv_d);
-            diff = (f32x2){fminf(fmaxf(t.x, 0.0f), 1.0f), fminf(fmaxf(t.y, 0.0f), 1.0f)};
-        } else diff = max0(-No);
-        f32x2 hx = p.Vx * dist - ox, hy = p.Vy * dist - oy, hz = p.Vz * dist - oz;
-        f32x2 inv_h = rsq2(hx * hx + hy * hy + hz * hz);
-        const f32x2 st = (p.NV * dist - No) * inv_h;
-        f32x2 sp = (f32x2){fminf(fmaxf(st.x, 0.0f), 1.0f), fminf(fmaxf(st.y, 0.0f), 1.0f)};
-        f32x2 s2 = sp * sp, s4 = s2 * s2;
-        // the lights' sum is kept apart from the base colour and multiplied in once after the loop
-        // (base * sum(c_l * w_l) for sum(base * c_l * w_l): three packed multiplies less per light)
-        f32x2 w = (s4 * s4 + diff) * inten;
-        p.ar += splat2(cr) * w;
-        p.ag += splat2(cg) * w;
-        p.ab += splat2(cb) * w;
-    };
-    if (L.kind == RND_LIGHT_DIRECTIONAL) {
-        const f32x2 ox = splat2(L.dir[0]), oy = splat2(L.dir[1]), oz = splat2(L.dir[2]);
-        float i0 = L.color[3], i1 = L.color[3];
-        if constexpr (kShadows) {
-            if ((uint32_t)L.shadow_index >= kLdsShadowSets) {       // (uniform over the wave) none, or beyond the LDS copy: one by one
-                if (p.lit0) i0 = L.color[3] * (1.0f - shadow_term(sets, L, fc, p.fx.x, p.fy.x, p.fz.x, p.Nx.x, p.Ny.x, p.Nz.x));
-                if (p.lit1) i1 = L.color[3] * (1.0f - shadow_term(sets, L, fc, p.fx.y, p.fy.y, p.fz.y, p.Nx.y, p.Ny.y, p.Nz.y));
+    const f32x2 No = p.Nx * ox + p.Ny * oy + p.Nz * oz;
+    f32x2 diff;
+    if constexpr (kPoint) diff = sat2(-(No * inv_d));
+    else diff = max0(-No);
+    const f32x2 hx = p.Vx * dist - ox, hy = p.Vy * dist - oy, hz = p.Vz * dist - oz;
+    const f32x2 inv_h = rsq2(hx * hx + hy * hy + hz * hz);
+    const f32x2 sp = sat2((p.NV * dist - No) * inv_h);
+    const f32x2 s2 = sp * sp, s4 = s2 * s2;
+    // the lights' sum is kept apart from the base colour and multiplied in once after the loop
+    const f32x2 w = (s4 * s4 + diff) * inten;
+    p.ar += splat2(cr) * w;
+    p.ag += splat2(cg) * w;
+    p.ab += splat2(cb) * w;
+}
+__device__ __forceinline__ void add_point_pair(const f32x4 a, const f32x4 b, PixelPair& p) {
+#pragma clang fp contract(fast)
+    const f32x2 ox = p.fx - splat2(a.x), oy = p.fy - splat2(a.y), oz = p.fz - splat2(a.z);
+    const f32x2 d2 = ox * ox + oy * oy + oz * oz;
+    const f32x2 inv_d = rsq2(d2);
+    const f32x2 dist = d2 * inv_d;
+    const f32x2 lin = sat2(splat2(1.0f) - dist * splat2(b.w));
+    light_pair_finish<true>(p, b.x, b.y, b.z, ox, oy, oz, inv_d, dist, (lin * lin) * (splat2(3.0f) - splat2(2.0f) * lin));
+}
+// a directional light: a = its direction, b.xyz = colour * intensity, `set` = its cascade set or -1
+template <bool kShadows>
+__device__ __forceinline__ void add_directional_pair(const f32x4 a, const f32x4 b, int32_t set, PixelPair& p,
+                                                     const ShadowSet* __restrict__ sets, const ShadowSet* lds_sets, FrameConstRef fc) {
+    float i0 = 1.0f, i1 = 1.0f;
+    if constexpr (kShadows) {
+        if (set >= 0) {                                            // (uniform over the wave)
+            if ((uint32_t)set >= kLdsShadowSets) {                 // beyond the LDS copy: one by one
+                if (p.lit0) i0 = 1.0f - light_occlusion(sets, set, fc, p.fx.x, p.fy.x, p.fz.x, p.Nx.x, p.Ny.x, p.Nz.x, a.x, a.y, a.z);
+                if (p.lit1) i1 = 1.0f - light_occlusion(sets, set, fc, p.fx.y, p.fy.y, p.fz.y, p.Nx.y, p.Ny.y, p.Nz.y, a.x, a.y, a.z);
             } else {
-                const ShadowSet& S = lds_sets[L.shadow_index];
-                const ShadowProbe q0 = shadow_probe(S, fc, p.fx.x, p.fy.x, p.fz.x, p.Nx.x, p.Ny.x, p.Nz.x, L.dir[0], L.dir[1], L.dir[2]);
-                const ShadowProbe q1 = shadow_probe(S, fc, p.fx.y, p.fy.y, p.fz.y, p.Nx.y, p.Ny.y, p.Nz.y, L.dir[0], L.dir[1], L.dir[2]);
+                const ShadowSet& S = lds_sets[set];
+                const ShadowProbe q0 = shadow_probe(S, fc, p.fx.x, p.fy.x, p.fz.x, p.Nx.x, p.Ny.x, p.Nz.x, a.x, a.y, a.z);
+                const ShadowProbe q1 = shadow_probe(S, fc, p.fx.y, p.fy.y, p.fz.y, p.Nx.y, p.Ny.y, p.Nz.y, a.x, a.y, a.z);
                 uint32_t t0[9], t1[9], in0, in1;
                 shadow_taps_issue(q0, t0, in0);
                 shadow_taps_issue(q1, t1, in1);
-                i0 = L.color[3] * (1.0f - shadow_taps_count(q0, t0, in0));
-                i1 = L.color[3] * (1.0f - shadow_taps_count(q1, t1, in1));
+                i0 = 1.0f - shadow_taps_count(q0, t0, in0);
+                i1 = 1.0f - shadow_taps_count(q1, t1, in1);
             }
         }
-        finish(std::false_type{}, ox, oy, oz, splat2(1.0f), splat2(1.0f), (f32x2){i0, i1});
-    } else {
-        f32x2 ox = p.fx - splat2(L.pos[0]), oy = p.fy - splat2(L.pos[1]), oz = p.fz - splat2(L.pos[2]);
-        f32x2 d2 = ox * ox + oy * oy + oz * oz;
-        f32x2 inv_d = rsq2(d2);
-        f32x2 dist = d2 * inv_d;
-        f32x2 lin = splat2(1.0f) - dist * splat2(L.inv_radius);
-        lin = (f32x2){fminf(fmaxf(lin.x, 0.0f), 1.0f), fminf(fmaxf(lin.y, 0.0f), 1.0f)};
-        finish(std::true_type{}, ox, oy, oz, inv_d, dist, ((lin * lin) * (splat2(3.0f) - splat2(2.0f) * lin)) * splat2(L.color[3]));
     }
+    light_pair_finish<false>(p, b.x, b.y, b.z, splat2(a.x), splat2(a.y), splat2(a.z), splat2(1.0f), splat2(1.0f), (f32x2){i0, i1});
 }
+#endif
 
-// one light through scalar loads (its index is wave-uniform)
+// one light through scalar loads (its index is wave-uniform): the per-fragment path of the builds without RND_FAST_SHADE
 __device__ __forceinline__ GpuLight load_light_uniform(const GpuLight* lights, uint32_t li) {
     typedef const __attribute__((address_space(4))) GpuLight* cptr_light;
     cptr_light lp = (cptr_light)lights + li;
@@ -2042,65 +2041,115 @@ __device__ __forceinline__ GpuLight load_light_uniform(const GpuLight* lights, u
     L.pad[0] = L.pad[1] = 0;
     return L;
 }
+
+// -DRND_SHADE_PROFILE: per-phase cycle stamps of k_shade's waves, summed into g_shade_prof (64 slots x 16 phases);
+// shade_profile_dump() prints cycles per wave and phase (called when a context is destroyed).  Development aid only.
+#ifdef RND_SHADE_PROFILE
+__device__ unsigned long long g_shade_prof[64][16];
+#define RND_PROF_DECL unsigned long long prof_t_ = clock64(); unsigned long long prof_acc_[12] = {}
+#define RND_PROF(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = clock64(); prof_acc_[k] += t_ - prof_t_; prof_t_ = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define RND_PROF_FLUSH do { if (lane == 0) { for (int q_ = 0; q_ < 12; ++q_) atomicAdd(&g_shade_prof[blockIdx.x & 63u][q_], prof_acc_[q_]); atomicAdd(&g_shade_prof[blockIdx.x & 63u][15], 1ull); } } while (0)
+void shade_profile_dump() {
+    static unsigned long long h[64][16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_shade_prof), sizeof h) != hipSuccess) return;
+    unsigned long long sum[16] = {};
+    for (auto& row : h) for (int k = 0; k < 16; ++k) sum[k] += row[k];
+    if (!sum[15]) return;
+    fprintf(stderr, "k_shade profile: %llu waves; cycles per wave by phase:", sum[15]);
+    unsigned long long all = 0;
+    for (int k = 0; k < 12; ++k) { fprintf(stderr, " [%d] %.0f", k, (double)sum[k] / (double)sum[15]); all += sum[k]; }
+    fprintf(stderr, "  total %.0f\n", (double)all / (double)sum[15]);
+    memset(h, 0, sizeof h);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_shade_prof), h, sizeof h);
+}
+#else
+#define RND_PROF_DECL
+#define RND_PROF(k)
+#define RND_PROF_FLUSH
+void shade_profile_dump() {}
 #endif
 
-// PPT pixels per lane: a workgroup shades 256*PPT consecutive pixels (8*PPT rows) of one tile.
+// A workgroup shades one part of a tile: 512 consecutive pixels (16 rows), two pixels per lane.
 // kShadows ("full" variant): the frame has directional lights with cascade sets or textured draw
 // items; both cost registers, so frames without them run the variant compiled without them.
-// kSamples: 1, or 4 (MSAA, PPT 1): phases A-C run once per sample plane — the fragment of the sample's
-// winning triangle is shaded at the pixel centre, exactly as the reference's per-pixel fragment stage,
+// kSamples: 1, or 4 (MSAA; a part is 256 pixels): phases A-C run once per pair of sample planes — the fragment of the
+// sample's winning triangle is shaded at the pixel centre, exactly as the reference's per-pixel fragment stage,
 // and re-used while consecutive samples hold the same triangle — each sample keeps the f16 colour,
 // and the pixel gets their mean (the resolve attachment, visual_server.rs:1134-1153).
-template <int PPT, bool kShadows, int kSamples, bool kStored>
+// Dynamic LDS: the frame's lights as ShadeLight (32 B each), then whatever the launch adds to set the occupancy.
+template <bool kShadows, int kSamples, bool kStored>
 // (waves per SIMD the variants are compiled for: the plain one 7, the full one 5 — 95 VGPRs without a spill where the
 // compiler left alone took 101 and with them a fifth wave: C3 + sun shade 0.268 -> 0.241 ms —, plain MSAA 5 (seven
 // spilled dwords at 96 VGPRs against 102 at four waves: C3 MSAA x4 shade 0.72 -> 0.68 ms); the full MSAA variant spills
 // 29 at 4 and keeps its 3)
-__global__ __launch_bounds__(256, PPT != 2 ? 1 : (kShadows ? (kSamples > 1 ? 1 : 5) : (kSamples > 1 ? 5 : 7))) void k_shade(FrameBuffers fb) {
+__global__ __launch_bounds__(256, kShadows ? (kSamples > 1 ? 1 : 5) : (kSamples > 1 ? 5 : 7)) void k_shade(FrameBuffers fb, uint32_t n_parts) {
     FrameConstRef fc = frame_const_ref(fb.frame_const);
-    static_assert(kSamples == 1 || PPT == 2, "the MSAA variant shades one pixel per lane, two of its samples at a time");
-    constexpr uint32_t kPix = kSamples > 1 ? 1u : (uint32_t)PPT;        // pixels per lane
-    __shared__ GpuLight s_lights[kMaxLights];
+    constexpr uint32_t PPT = 2;                                         // fragments per lane in flight: two pixels, or two samples of one
+    constexpr uint32_t kPix = kSamples > 1 ? 1u : PPT;                  // pixels per lane
+    extern __shared__ __align__(16) unsigned char s_dyn[];
     __shared__ uint32_t s_bases[kLdsItems + 1];
     __shared__ float s_lut[kShadows ? 512 : 1];     // texel decode table (see FetchSrgb8), full variant only
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const TileRef ref = fb.launch_order[blockIdx.x % fb.n_owned];
-    const uint32_t part = (blockIdx.x / fb.n_owned) * (256u * kPix);    // first tile-local pixel of this workgroup
-    const uint32_t tile_x0 = (ref.tile % fc.tiles_x) * kTile, tile_y0 = (ref.tile / fc.tiles_x) * kTile;
-    const unsigned long long* vis0 = reinterpret_cast<const unsigned long long*>(fb.vis) + (size_t)ref.tile * kTilePixels;
+    // The frame's shape comes by value (FrameBuffers::dims), not from the constants in device memory: what a workgroup
+    // needs before its first loads can go out — the visibility words, the tables for LDS, the counters — then depends
+    // on the kernel arguments alone and is one round trip, where the tile list and the constants were two more in
+    // front of it (a workgroup's set-up was 11 k of the 33 k cycles a wave spends on a part).
+    const uint32_t n_lights = min(fb.dims.n_lights, kMaxLights), n_items = fb.dims.n_items;
+    ShadeLight* const s_light = reinterpret_cast<ShadeLight*>(s_dyn);
+    // Part p = blockIdx.x: XCD p % 8 (where the workgroup runs),
+    // then which sixteen rows of the tile, then the tile's number on its XCD: every XCD shades one contiguous run of
+    // the row-major list of owned tiles (rebuild_tiles keeps the same order for the other kernels), in closed form.
+    constexpr uint32_t kPartShift = kSamples > 1 ? 2u : 1u;            // log2(parts per tile)
+    auto locate = [&](uint32_t p, uint32_t& tile, uint32_t& compact, uint32_t& first) {
+        const uint32_t xcd = p & (kXcds - 1u), sub = (p >> 3) & ((1u << kPartShift) - 1u), j = p >> (3u + kPartShift);
+        const uint32_t q = fb.n_owned >> 3, r = fb.n_owned & (kXcds - 1u);
+        const uint32_t idx = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + j;
+        compact = idx; first = sub * (256u * kPix);
+        tile = idx;
+        if (fb.dims.world > 1u) {
+            // the idx-th owned tile of a stripe partition: full-width stripes of kOwnerGroup tile rows, dealt round-robin
+            const uint32_t row = fb.dims.tiles_x_magic ? __umulhi(idx, fb.dims.tiles_x_magic) : idx, tx = idx - row * fb.dims.tiles_x;
+            tile = (((row / kOwnerGroup) * fb.dims.world + fb.dims.rank) * kOwnerGroup + row % kOwnerGroup) * fb.dims.tiles_x + tx;
+        }
+        return p < n_parts && j < q + (xcd < r ? 1u : 0u);       // (the last tiles of an XCD's run may not exist)
+    };
+    auto part_vis = [&](uint32_t tile, uint32_t first, uint32_t smp_plane, uint32_t k) {
+        const unsigned long long* v = reinterpret_cast<const unsigned long long*>(fb.vis) + (size_t)tile * kTilePixels + (size_t)smp_plane * fb.vis_stride;
+        return v[first + wave * (64u * kPix) + (kSamples > 1 ? 0u : k * 64u) + lane];
+    };
+    RND_PROF_DECL;
+    uint32_t tile_s, compact_s, part;
+    if (!locate(blockIdx.x, tile_s, compact_s, part)) return;          // (uniform over the workgroup)
     // The visibility words of the lane's pixels (of its first two samples under MSAA) are requested before anything else:
     // the first of the fragment phase's dependent round trips then runs beside the workgroup's set-up (tables to LDS,
     // counters, barrier) instead of after it.
     unsigned long long key_first[PPT];
 #pragma unroll
-    for (uint32_t k = 0; k < PPT; ++k)
-        key_first[k] = (vis0 + (size_t)(kSamples > 1 ? k : 0u) * fb.vis_stride)[part + wave * (64u * kPix) + (kSamples > 1 ? 0u : k * 64u) + lane];
-    if constexpr (kShadows) { s_lut[tid] = fb.srgb_lut[tid]; s_lut[256u + tid] = fb.srgb_lut[256u + tid]; }
+    for (uint32_t k = 0; k < PPT; ++k) key_first[k] = part_vis(tile_s, part, kSamples > 1 ? k : 0u, k);
+    // The tables for LDS: every load first, then one wait, then the LDS writes and the barrier — ONE round trip.  (The
+    // copy loops of round 2 each waited for their own loads, and with them for the visibility words above: four round
+    // trips in a row under the kernel's own gather traffic, 11 k of the 33 k cycles of a wave's life.)
+    const bool bases_in_lds = n_items <= kLdsItems;
+    uint32_t base_v = 0u;
+    if (bases_in_lds && tid <= n_items) base_v = fb.tri_bases[tid];
+    f32x4 l0 = {0.0f, 0.0f, 0.0f, 0.0f}, l1 = l0, l2 = l0, l3 = l0;
+    if (tid < n_lights) {
+        const f32x4* lp = reinterpret_cast<const f32x4*>(fb.lights + tid);
+        l0 = lp[0]; l1 = lp[1]; l2 = lp[2]; l3 = lp[3];
+    }
+    float lut0 = 0.0f, lut1 = 0.0f;
+    if constexpr (kShadows) { lut0 = fb.srgb_lut[tid]; lut1 = fb.srgb_lut[256u + tid]; }
     __shared__ ShadowSet s_sets[kShadows ? kLdsShadowSets : 1];      // the first cascade sets (matrices, layer pointers), full variant only
-    if constexpr (kShadows) {
-        const uint32_t n_words = min(fb.n_shadow_sets, kLdsShadowSets) * (uint32_t)(sizeof(ShadowSet) / 4);
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(fb.shadow_sets);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(s_sets);
-        for (uint32_t k = tid; k < n_words; k += 256u) dst[k] = src[k];
-    }
-    const bool bases_in_lds = fc.n_items <= kLdsItems;
-    if (bases_in_lds)
-        for (uint32_t k = tid; k <= fc.n_items; k += 256u) s_bases[k] = fb.tri_bases[k];
-    {
-        const uint32_t n_words = fc.n_lights * (uint32_t)(sizeof(GpuLight) / 4);
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(fb.lights);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(s_lights);
-        for (uint32_t k = tid; k < n_words; k += 256u) dst[k] = src[k];
-    }
     // A frame whose geometry phase overflowed an internal stream (records, clip queue, bin entries: triangles were
     // dropped) is not presented: nothing is written, the image keeps the previous frame.  The host learns of it
     // from the report (no synchronization) and has grown the streams by the next frame; rnd_finish re-runs it.
     {
+        typedef const __attribute__((address_space(4))) FrameCounters* cptr_counters;      // scalar loads
         uint32_t ovf = 0, n_rec = 0, n_clip = 0, n_ent = 0;
-        for (uint32_t s = 0; s < fb.n_counter_sets; ++s) {          // wave-uniform: scalar loads
+        for (uint32_t s = 0; s < fb.n_counter_sets; ++s) {
             if (s < 64u && !((fb.ran_mask >> s) & 1ull)) continue;
-            const FrameCounters& c = fb.all_counters[s];
-            ovf |= c.overflow; n_rec = max(n_rec, c.n_records); n_clip = max(n_clip, c.n_clip); n_ent = max(n_ent, c.n_entries);
+            cptr_counters c = (cptr_counters)fb.all_counters + s;
+            ovf |= c->overflow; n_rec = max(n_rec, c->n_records); n_clip = max(n_clip, c->n_clip); n_ent = max(n_ent, c->n_entries);
         }
         if (blockIdx.x == 0 && tid == 0 && fb.report) {
             volatile FrameReport* r = fb.report;
@@ -2110,8 +2159,33 @@ __global__ __launch_bounds__(256, PPT != 2 ? 1 : (kShadows ? (kSamples > 1 ? 1 :
         }
         if (ovf & 7u) return;          // (uniform over the grid; before any barrier)
     }
+    if constexpr (kShadows) {
+        s_lut[tid] = lut0; s_lut[256u + tid] = lut1;
+        const uint32_t n_words = min(fb.n_shadow_sets, kLdsShadowSets) * (uint32_t)(sizeof(ShadowSet) / 4);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(fb.shadow_sets);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(s_sets);
+        for (uint32_t k = tid; k < n_words; k += 256u) dst[k] = src[k];
+    }
+    if (bases_in_lds) {
+        if (tid <= n_items) s_bases[tid] = base_v;
+        for (uint32_t k = tid + 256u; k <= n_items; k += 256u) s_bases[k] = fb.tri_bases[k];
+    }
+    static_assert(kMaxLights <= 256, "one thread per light");
+    static_assert(sizeof(GpuLight) == 64, "a light is four 16-byte loads");
+    if (tid < n_lights) {
+        // l0 = pos.xyz, radius; l1 = dir.xyz, kind; l2 = colour rgb, intensity; l3 = shadow_index, inv_radius, -, -
+        const bool directional = __float_as_uint(l1.w) == RND_LIGHT_DIRECTIONAL;
+        f32x4* dst = reinterpret_cast<f32x4*>(s_light + tid);
+        dst[0] = directional ? (f32x4){l1.x, l1.y, l1.z, -1.0f} : (f32x4){l0.x, l0.y, l0.z, fmaxf(l0.w, 0.0f)};
+        dst[1] = (f32x4){l2.x * l2.w, l2.y * l2.w, l2.z * l2.w, l3.y};
+    }
     __syncthreads();
+    RND_PROF(0);
 
+  {
+    const uint32_t tile_ty = fb.dims.tiles_x_magic ? __umulhi(tile_s, fb.dims.tiles_x_magic) : tile_s;
+    const uint32_t tile_x0 = (tile_s - tile_ty * fb.dims.tiles_x) * kTile, tile_y0 = tile_ty * kTile;
+    const unsigned long long* vis0 = reinterpret_cast<const unsigned long long*>(fb.vis) + (size_t)tile_s * kTilePixels;
     PixelInputs px[PPT];
     unsigned long long key[PPT];
     bool covered[PPT];
@@ -2123,15 +2197,15 @@ __global__ __launch_bounds__(256, PPT != 2 ? 1 : (kShadows ? (kSamples > 1 ? 1 :
     float keep[PPT][3] = {};        // MSAA: the colour each of the lane's two samples was shaded to in the previous pair
     unsigned long long key0 = 0;
   // MSAA: the lane's two "pixels" are two samples of ONE pixel (samples 0, 1, then 2, 3), so that the light loop runs
-  // on the packed pair path as it does for two pixels
+  // on the pair path as it does for two pixels
   for (int smp = 0; smp < kSamples; smp += (kSamples > 1 ? PPT : 1)) {
     // phase A: fragment inputs of this lane's pixels.  The visibility words of all of them first, then — the usual
     // case: every covered pixel of the wave, over all of the lane's pixels, belongs to ONE draw item — each stage of
-    // the fragment fetch for all pixels before the next stage (PPT <= 2: the loaded data of two pixels is 42
+    // the fragment fetch for all pixels before the next stage (the loaded data of two pixels is 42
     // registers), so that the lane's dependent round trips are four (word, item, indices, corners) and not four per pixel.
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
     uint32_t id[PPT], pi[PPT], pj[PPT], it[PPT];
-    PixelInputs fresh[PPT];
+    PixelInputs fresh[PPT] = {};
 #pragma unroll
     for (uint32_t k = 0; k < PPT; ++k) {
         const unsigned long long* vis = vis0 + (size_t)(kSamples > 1 ? (uint32_t)smp + k : 0u) * fb.vis_stride;
@@ -2148,7 +2222,7 @@ __global__ __launch_bounds__(256, PPT != 2 ? 1 : (kShadows ? (kSamples > 1 ? 1 :
             reuse[k] = smp > 0 && id[k] == prev_id[k];
             prev_id[k] = id[k];
         }
-        covered[k] = pi[k] < fc.width && pj[k] < fc.height && id[k] != RND_NONE;
+        covered[k] = pi[k] < fb.dims.width && pj[k] < fb.dims.height && id[k] != RND_NONE;
         if constexpr (kSamples > 1) covered[k] = covered[k] && !reuse[k];
         if (covered[k] && !guard(id[k] < fc.n_tris, fb.counters, kGuardShade)) covered[k] = false;
         // the fragment's inputs go to `fresh`, left unset on lanes without a fragment; the defaults are
@@ -2157,24 +2231,25 @@ __global__ __launch_bounds__(256, PPT != 2 ? 1 : (kShadows ? (kSamples > 1 ? 1 :
         it[k] = 0;
     }
     bool staged = false;
-    if constexpr (PPT == 2) {
+    {
         const bool any_k = covered[0] || covered[1];
         const unsigned long long cov = __ballot(any_k);
+        RND_PROF(1);
         if (cov) {
             // the draw item of the wave's first fragment, looked up once for the wave (all lanes compare one range of
             // the base table each; tables of more than 64 items: that lane's own binary search), then every other
             // fragment is tested against its triangle range: two instructions a pixel instead of a search
             uint32_t lead_s;
-            if (bases_in_lds && fc.n_items <= 64u) {
+            if (bases_in_lds && n_items <= 64u) {
                 uint32_t id_s;
                 uniform_pick(covered[0] ? id[0] : id[1], cov, id_s);
-                lead_s = find_item_wave(s_bases, fc.n_items, id_s, lane);
+                lead_s = find_item_wave(s_bases, n_items, id_s, lane);
                 asm volatile("" : "+s"(lead_s));
             } else {
                 const uint32_t some = covered[0] ? id[0] : id[1];
-                uniform_pick(any_k ? (bases_in_lds ? find_item(s_bases, fc.n_items, some) : find_item(fb.tri_bases, fc.n_items, some)) : 0u, cov, lead_s);
+                uniform_pick(any_k ? (bases_in_lds ? find_item(s_bases, n_items, some) : find_item(fb.tri_bases, n_items, some)) : 0u, cov, lead_s);
             }
-            if (lead_s < fc.n_items) {
+            if (lead_s < n_items) {
                 const DrawItem d = load_item_uniform(fb.items, lead_s);
                 const bool others = (covered[0] && id[0] - d.tri_base >= d.n_tris) || (covered[1] && id[1] - d.tri_base >= d.n_tris);
                 if (__ballot(others) == 0ull && world_from_clip(d, fc)) {
@@ -2184,11 +2259,14 @@ __global__ __launch_bounds__(256, PPT != 2 ? 1 : (kShadows ? (kSamples > 1 ? 1 :
                     // (a pixel without a fragment fetches the item's first triangle and drops it)
 #pragma unroll
                     for (uint32_t k = 0; k < PPT; ++k) frag_indices(d, covered[k] ? id[k] : d.tri_base, f[k], ok[k]);
+                    RND_PROF(2);
 #pragma unroll
                     for (uint32_t k = 0; k < PPT; ++k) frag_fetch<kShadows, kStored>(d, fc, fb.clip, f[k], ok[k] || !covered[k], fb.counters);
+                    RND_PROF(3);
+                    // (for every lane: one without a fragment finishes the triangle it fetched, straight-line)
 #pragma unroll
-                    for (uint32_t k = 0; k < PPT; ++k)
-                        if (covered[k]) frag_finish<kShadows, kStored>(d, fc, fb.clip, fb.textures, s_lut, pi[k], pj[k], f[k], fresh[k]);
+                    for (uint32_t k = 0; k < PPT; ++k) frag_finish<kShadows, kStored>(d, fc, fb.clip, fb.textures, s_lut, pi[k], pj[k], f[k], fresh[k]);
+                    RND_PROF(4);
                 }
             }
         } else staged = true;        // nothing covered
@@ -2196,7 +2274,7 @@ __global__ __launch_bounds__(256, PPT != 2 ? 1 : (kShadows ? (kSamples > 1 ? 1 :
     if (!staged) {
 #pragma unroll
         for (uint32_t k = 0; k < PPT; ++k)
-            if (covered[k]) it[k] = bases_in_lds ? find_item(s_bases, fc.n_items, id[k]) : find_item(fb.tri_bases, fc.n_items, id[k]);
+            if (covered[k]) it[k] = bases_in_lds ? find_item(s_bases, n_items, id[k]) : find_item(fb.tri_bases, n_items, id[k]);
 #pragma unroll
         for (uint32_t k = 0; k < PPT; ++k) {
             const unsigned long long cov = __ballot(covered[k]);
@@ -2221,6 +2299,104 @@ __global__ __launch_bounds__(256, PPT != 2 ? 1 : (kShadows ? (kSamples > 1 ? 1 :
             }
         }
     }
+    // phase B + C, per wave: the bounding box of the wave's lit fragments (4 rows of the
+    // tile), then for each group of 64 lights one lane tests one light against it and the wave
+    // walks the surviving bits in ascending order.  A point light whose sphere misses the box adds
+    // exactly zero to every fragment in it (distance > radius discards), so dropping it changes
+    // nothing, and the lights keep their original order.
+#if RND_FAST_SHADE
+    // Straight-line from here to the light loop: a lane without a fragment computes on whatever `fresh` holds for it
+    // (zeros, or the item's first triangle) and its results are dropped by the selects behind the loop — defaults
+    // written up front made every merge of the paths above re-materialize a dozen registers per pixel.
+    PixelPair pp;
+    {
+#pragma clang fp contract(fast)
+#define RND_PAIR(f) pp.f = (f32x2){fresh[0].f, fresh[1].f}
+        RND_PAIR(fx); RND_PAIR(fy); RND_PAIR(fz); RND_PAIR(Nx); RND_PAIR(Ny); RND_PAIR(Nz); RND_PAIR(br); RND_PAIR(bg); RND_PAIR(bb);
+#undef RND_PAIR
+        pp.lit0 = covered[0] && fresh[0].lit; pp.lit1 = covered[1] && fresh[1].lit;
+        // unit vector to the camera
+        const f32x2 vx = splat2(fc.cam_pos[0]) - pp.fx, vy = splat2(fc.cam_pos[1]) - pp.fy, vz = splat2(fc.cam_pos[2]) - pp.fz;
+        const f32x2 inv_v = rsq2(vx * vx + vy * vy + vz * vz);
+        pp.Vx = vx * inv_v; pp.Vy = vy * inv_v; pp.Vz = vz * inv_v;
+        pp.ar = pp.ag = pp.ab = splat2(0.0f);
+        pp.NV = pp.Nx * pp.Vx + pp.Ny * pp.Vy + pp.Nz * pp.Vz;
+    }
+    const bool any_lit = __ballot(pp.lit0 || pp.lit1) != 0ull;
+    RND_PROF(5);
+    if (any_lit) {
+        if (pp.lit0) { lo[0] = hi[0] = pp.fx.x; lo[1] = hi[1] = pp.fy.x; lo[2] = hi[2] = pp.fz.x; }
+        if (pp.lit1) {
+            lo[0] = fminf(lo[0], pp.fx.y); lo[1] = fminf(lo[1], pp.fy.y); lo[2] = fminf(lo[2], pp.fz.y);
+            hi[0] = fmaxf(hi[0], pp.fx.y); hi[1] = fmaxf(hi[1], pp.fy.y); hi[2] = fmaxf(hi[2], pp.fz.y);
+        }
+        wave_box(lo, hi);
+        RND_PROF(6);
+        // every group's verdicts first (the box dies here), then the walk
+        unsigned long long km_g[kMaxLights / 64], dm_g[kMaxLights / 64];
+#pragma unroll
+        for (uint32_t g = 0; g < kMaxLights / 64; ++g) {
+            km_g[g] = 0ull; dm_g[g] = 0ull;
+            if (g * 64u < n_lights) {                               // (uniform)
+                // one lane, one light: kept when it is directional or its sphere reaches the box
+                bool keep_light = false, directional = false;
+                if (g * 64u + lane < n_lights) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(s_light + g * 64u + lane);
+                    directional = a.w < 0.0f;
+                    float dd = 0.0f;
+                    const float pos[3] = {a.x, a.y, a.z};
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        float e = fmaxf(fmaxf(lo[c] - pos[c], pos[c] - hi[c]), 0.0f);
+                        dd += e * e;
+                    }
+                    float rr = a.w * 1.001f + 1.0e-6f;      // conservative: never drop a light that could pass
+                    keep_light = directional || dd <= rr * rr;
+                }
+                km_g[g] = __ballot(keep_light); dm_g[g] = __ballot(directional);
+            }
+        }
+        static_assert(kMaxLights / 64 == 4, "four groups of 64 lights");
+        RND_PROF(7);
+        for (uint32_t g = 0; g * 64u < n_lights; ++g) {
+            const unsigned long long dm = g == 0u ? dm_g[0] : g == 1u ? dm_g[1] : g == 2u ? dm_g[2] : dm_g[3];
+            unsigned long long km = g == 0u ? km_g[0] : g == 1u ? km_g[1] : g == 2u ? km_g[2] : km_g[3];
+            if (km == 0ull) continue;
+            // the light's 32 bytes from LDS, all lanes at one address: its fields arrive in VGPRs.
+            for (; km; km &= km - 1ull) {
+                const uint32_t bit = (uint32_t)(__ffsll((long long)km) - 1);
+                const uint32_t li = __builtin_amdgcn_readfirstlane(g * 64u + bit);
+                const f32x4 a = reinterpret_cast<const f32x4*>(s_light + li)[0], b = reinterpret_cast<const f32x4*>(s_light + li)[1];
+                if ((dm >> bit) & 1ull) {
+                    int32_t set = -1;
+                    if constexpr (kShadows) {
+                        typedef const __attribute__((address_space(4))) GpuLight* cptr_light;
+                        set = ((cptr_light)fb.lights + li)->shadow_index;
+                    }
+                    add_directional_pair<kShadows>(a, b, set, pp, fb.shadow_sets, s_sets, fc);
+                } else add_point_pair(a, b, pp);
+            }
+        }
+    }
+    RND_PROF(8);
+    {
+        // colour = base * (ambient + lights' sum) for a lit fragment, base for an unlit one (render_mesh.wgsl:97-106),
+        // else what the pixel keeps: the clear colour, or (MSAA) the colour the sample was shaded to before
+#pragma clang fp contract(fast)
+        const float ar = fc.ambient[0] * fc.ambient[3], ag = fc.ambient[1] * fc.ambient[3], ab = fc.ambient[2] * fc.ambient[3];
+        const float tr[2] = {pp.lit0 ? ar + pp.ar.x : 1.0f, pp.lit1 ? ar + pp.ar.y : 1.0f};
+        const float tg[2] = {pp.lit0 ? ag + pp.ag.x : 1.0f, pp.lit1 ? ag + pp.ag.y : 1.0f};
+        const float tb[2] = {pp.lit0 ? ab + pp.ab.x : 1.0f, pp.lit1 ? ab + pp.ab.y : 1.0f};
+        const float br[2] = {pp.br.x, pp.br.y}, bg[2] = {pp.bg.x, pp.bg.y}, bb[2] = {pp.bb.x, pp.bb.y};
+#pragma unroll
+        for (uint32_t k = 0; k < PPT; ++k) {
+            const bool again = kSamples > 1 && reuse[k];
+            px[k].cr = covered[k] ? br[k] * tr[k] : (again ? keep[k][0] : fc.clear_hdr[0]);
+            px[k].cg = covered[k] ? bg[k] * tg[k] : (again ? keep[k][1] : fc.clear_hdr[1]);
+            px[k].cb = covered[k] ? bb[k] * tb[k] : (again ? keep[k][2] : fc.clear_hdr[2]);
+        }
+    }
+#else
 #pragma unroll
     for (uint32_t k = 0; k < PPT; ++k) {
         // (every field is set here on every path: of a sample pair only the three colours in `keep` live on to the next)
@@ -2231,105 +2407,35 @@ __global__ __launch_bounds__(256, PPT != 2 ? 1 : (kShadows ? (kSamples > 1 ? 1 :
             px[k].cr = again ? keep[k][0] : fc.clear_hdr[0]; px[k].cg = again ? keep[k][1] : fc.clear_hdr[1];
             px[k].cb = again ? keep[k][2] : fc.clear_hdr[2];
         }
-        if (covered[k]) {
-            if (px[k].lit) {
-                lo[0] = fminf(lo[0], px[k].fx); lo[1] = fminf(lo[1], px[k].fy); lo[2] = fminf(lo[2], px[k].fz);
-                hi[0] = fmaxf(hi[0], px[k].fx); hi[1] = fmaxf(hi[1], px[k].fy); hi[2] = fmaxf(hi[2], px[k].fz);
-            }
+        if (covered[k] && px[k].lit) {
+            lo[0] = fminf(lo[0], px[k].fx); lo[1] = fminf(lo[1], px[k].fy); lo[2] = fminf(lo[2], px[k].fz);
+            hi[0] = fmaxf(hi[0], px[k].fx); hi[1] = fmaxf(hi[1], px[k].fy); hi[2] = fmaxf(hi[2], px[k].fz);
         }
     }
-    // phase B + C, per wave: the bounding box of the wave's lit fragments (2*PPT rows of the
-    // tile), then for each group of 64 lights one lane tests one light against it and the wave
-    // walks the surviving bits in ascending order.  A point light whose sphere misses the box adds
-    // exactly zero to every fragment in it (distance > radius discards), so dropping it changes
-    // nothing, and the lights keep their original order.
     wave_box(lo, hi);
-#if RND_FAST_SHADE
-    PixelPair pp;
-    if constexpr (PPT == 2) {
-#define RND_PAIR(f) pp.f = (f32x2){px[0].f, px[1].f}
-        RND_PAIR(fx); RND_PAIR(fy); RND_PAIR(fz); RND_PAIR(Nx); RND_PAIR(Ny); RND_PAIR(Nz); RND_PAIR(Vx); RND_PAIR(Vy);
-        RND_PAIR(Vz); RND_PAIR(br); RND_PAIR(bg); RND_PAIR(bb); RND_PAIR(cr); RND_PAIR(cg); RND_PAIR(cb);
-#undef RND_PAIR
-        pp.lit0 = px[0].lit && (kSamples == 1 || covered[0]); pp.lit1 = px[1].lit && (kSamples == 1 || covered[1]);
-        pp.ar = pp.ag = pp.ab = splat2(0.0f);
-        pp.NV = pp.Nx * pp.Vx + pp.Ny * pp.Vy + pp.Nz * pp.Vz;
-    }
-#endif
     if (lo[0] <= hi[0]) {
-        for (uint32_t group = 0; group < fc.n_lights; group += 64u) {
-            bool keep = false;
-            if (group + lane < fc.n_lights) {
-                const GpuLight& L = s_lights[group + lane];
-                if (L.kind == RND_LIGHT_DIRECTIONAL) keep = true;
-                else {
-                    float dd = 0.0f;
+        for (uint32_t group = 0; group < n_lights; group += 64u) {
+            bool keep_light = false;
+            if (group + lane < n_lights) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(s_light + group + lane);
+                float dd = 0.0f;
+                const float pos[3] = {a.x, a.y, a.z};
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        float e = fmaxf(fmaxf(lo[c] - L.pos[c], L.pos[c] - hi[c]), 0.0f);
-                        dd += e * e;
-                    }
-                    float rr = L.radius * 1.001f + 1.0e-6f;      // conservative: never drop a light that could pass
-                    keep = dd <= rr * rr;
+                for (int c = 0; c < 3; ++c) {
+                    float e = fmaxf(fmaxf(lo[c] - pos[c], pos[c] - hi[c]), 0.0f);
+                    dd += e * e;
                 }
+                float rr = a.w * 1.001f + 1.0e-6f;
+                keep_light = a.w < 0.0f || dd <= rr * rr;
             }
-#if RND_FAST_SHADE && RND_SCALAR_LIGHTS
-            if constexpr (PPT == 2) {
-                // the next surviving light's 64 bytes are requested (scalar loads) before the current one is worked on
-                unsigned long long km = __ballot(keep);
-                if (km == 0ull) continue;
-                GpuLight cur = load_light_uniform(fb.lights, __builtin_amdgcn_readfirstlane(group + (uint32_t)(__ffsll((long long)km) - 1)));
-                km &= km - 1ull;
-                for (;;) {
-                    const bool more = km != 0ull;
-                    // (the last light is loaded a second time rather than branching around the load)
-                    const uint32_t ni = more ? group + (uint32_t)(__ffsll((long long)km) - 1) : 0u;
-                    const GpuLight nxt = load_light_uniform(fb.lights, __builtin_amdgcn_readfirstlane(ni));
-                    add_light_pair<kShadows>(cur, pp, fb.shadow_sets, s_sets, fc);
-                    if (!more) break;
-                    km &= km - 1ull;
-                    cur = nxt;
-                }
-                continue;
-            }
-#endif
-            for (unsigned long long km = __ballot(keep); km; km &= km - 1ull) {
-                // the whole light at once (16 B LDS reads, one wait) rather than field by field as the
-                // branches below get to them
-#if RND_SCALAR_LIGHTS
-                // the surviving light's index is wave-uniform: its 64 bytes come through one scalar load
-                typedef const __attribute__((address_space(4))) GpuLight* cptr_light;
+            for (unsigned long long km = __ballot(keep_light); km; km &= km - 1ull) {
                 const uint32_t li = __builtin_amdgcn_readfirstlane(group + (uint32_t)(__ffsll((long long)km) - 1));
-                cptr_light lp = (cptr_light)fb.lights + li;
-                GpuLight L;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) { L.pos[c] = lp->pos[c]; L.dir[c] = lp->dir[c]; }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) L.color[c] = lp->color[c];
-                L.radius = lp->radius; L.kind = lp->kind; L.shadow_index = lp->shadow_index; L.inv_radius = lp->inv_radius;
-#else
-                GpuLight L;
-                {
-                    const uint4* src = reinterpret_cast<const uint4*>(&s_lights[group + (uint32_t)(__ffsll((long long)km) - 1)]);
-                    uint4* dst = reinterpret_cast<uint4*>(&L);
-                    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
-                }
-#endif
-#if RND_FAST_SHADE
-                if constexpr (PPT == 2) { add_light_pair<kShadows>(L, pp, fb.shadow_sets, s_sets, fc); continue; }
-#endif
+                const GpuLight L = load_light_uniform(fb.lights, li);
 #pragma unroll
                 for (uint32_t k = 0; k < PPT; ++k)
                     if (px[k].lit && (kSamples == 1 || covered[k])) add_light<kShadows>(L, px[k], fb.shadow_sets, fc);
             }
         }
-    }
-#if RND_FAST_SHADE
-    if constexpr (PPT == 2) {
-        pp.cr += pp.br * pp.ar; pp.cg += pp.bg * pp.ag; pp.cb += pp.bb * pp.ab;
-        // (a lane without a lit fragment keeps its colour; so does a re-used sample: the one it was shaded to)
-        if (pp.lit0) { px[0].cr = pp.cr.x; px[0].cg = pp.cg.x; px[0].cb = pp.cb.x; }
-        if (pp.lit1) { px[1].cr = pp.cr.y; px[1].cg = pp.cg.y; px[1].cb = pp.cb.y; }
     }
 #endif
     if constexpr (kSamples > 1) {
@@ -2349,7 +2455,7 @@ __global__ __launch_bounds__(256, PPT != 2 ? 1 : (kShadows ? (kSamples > 1 ? 1 :
     for (uint32_t k = 0; k < kPix; ++k) {
         uint32_t local = part + wave * (64u * kPix) + k * 64u + lane;
         uint32_t i = tile_x0 + (local & (kTile - 1)), j = tile_y0 + (local / kTile);
-        bool inside = i < fc.width && j < fc.height;
+        bool inside = i < fb.dims.width && j < fb.dims.height;
         float hr = round_f16(px[k].cr), hg = round_f16(px[k].cg), hb = round_f16(px[k].cb);
         float r = hr, g = hg, b = hb;
         if (fc.tone == RND_TONE_MAPPING_REINHARD) {
@@ -2363,14 +2469,17 @@ __global__ __launch_bounds__(256, PPT != 2 ? 1 : (kShadows ? (kSamples > 1 ? 1 :
 #endif
         }
         uint32_t rgba = srgb8_f(r) | (srgb8_f(g) << 8) | (srgb8_f(b) << 16) | 0xFF000000u;
-        if (fb.tiles_rgba8) reinterpret_cast<uint32_t*>(fb.tiles_rgba8)[(size_t)ref.compact * kTilePixels + local] = inside ? rgba : 0u;
+        if (fb.tiles_rgba8) reinterpret_cast<uint32_t*>(fb.tiles_rgba8)[(size_t)compact_s * kTilePixels + local] = inside ? rgba : 0u;
         if (inside) {
-            size_t p = (size_t)j * fc.width + i;
+            size_t p = (size_t)j * fb.dims.width + i;
             if (fb.frame_rgba8) reinterpret_cast<uint32_t*>(fb.frame_rgba8)[p] = rgba;
             if (fb.packed) reinterpret_cast<unsigned long long*>(fb.packed)[p] = (key[k] & 0xFFFFFFFF00000000ull) | rgba;
             if (fb.hdr) { fb.hdr[p * 3] = hr; fb.hdr[p * 3 + 1] = hg; fb.hdr[p * 3 + 2] = hb; }
         }
     }
+    RND_PROF(9);
+  }
+    RND_PROF_FLUSH;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2683,27 +2792,26 @@ void launch_raster(const FrameBuffers& fb, const FrameConst& fc, const Capacitie
 }
 void launch_shade(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream) {
     if (!fb.n_owned) return;
-    static const int ppt = [] { const char* e = getenv("RND_SHADE_PPT"); int v = e ? atoi(e) : 2; return (v == 1 || v == 2 || v == 4) ? v : 1; }();
     const bool sh = fb.shadow_sets != nullptr || fb.has_textures;
-    // Unused dynamic LDS per workgroup.  The plain variant (72 VGPRs, 20 KB of LDS) is limited to seven workgroups a CU by
-    // its registers and to eight by its LDS; claiming 2 KB more makes LDS say seven as well, and with that the next frame's
-    // geometry kernels, which run beside this one, interleave better: 3110 -> 3320 frames/s at C3, this kernel's own time
-    // unchanged.  RND_SHADE_LDS_PAD overrides it for every variant (the occupancy experiments).
+    const bool ms = fc.n_samples == 4;
+    // Dynamic LDS: the lights (32 B each), the sRGB table, and an unused remainder that sets the occupancy.  The plain
+    // variant is limited to seven workgroups a CU by its registers; claiming LDS so that LDS says seven as well made the
+    // next frame's geometry kernels, which run beside this one, interleave better.
+    // RND_SHADE_LDS_PAD overrides the remainder for every variant (the occupancy experiments).
     static const int lds_env = [] { const char* e = getenv("RND_SHADE_LDS_PAD"); return e ? atoi(e) : -1; }();
-    const bool plain = fc.n_samples != 4 && ppt == 2 && !sh;
-    const unsigned pad = lds_env >= 0 ? (unsigned)lds_env : (plain ? 2048u : 0u);
-    if (fc.n_samples == 4) {
-        if (sh) hipLaunchKernelGGL((fb.clip ? k_shade<2, true, 4, true> : k_shade<2, true, 4, false>), dim3(fb.n_owned * 4), dim3(256), pad, stream, fb);
-        else hipLaunchKernelGGL((fb.clip ? k_shade<2, false, 4, true> : k_shade<2, false, 4, false>), dim3(fb.n_owned * 4), dim3(256), pad, stream, fb);
-    } else if (ppt == 4) {
-        if (sh) hipLaunchKernelGGL((fb.clip ? k_shade<4, true, 1, true> : k_shade<4, true, 1, false>), dim3(fb.n_owned), dim3(256), pad, stream, fb);
-        else hipLaunchKernelGGL((fb.clip ? k_shade<4, false, 1, true> : k_shade<4, false, 1, false>), dim3(fb.n_owned), dim3(256), pad, stream, fb);
-    } else if (ppt == 2) {
-        if (sh) hipLaunchKernelGGL((fb.clip ? k_shade<2, true, 1, true> : k_shade<2, true, 1, false>), dim3(fb.n_owned * 2), dim3(256), pad, stream, fb);
-        else hipLaunchKernelGGL((fb.clip ? k_shade<2, false, 1, true> : k_shade<2, false, 1, false>), dim3(fb.n_owned * 2), dim3(256), pad, stream, fb);
+    // one workgroup per part (512 pixels; 256 under MSAA); part numbers interleave the XCDs: see k_shade's locate
+    const uint32_t n_parts = (fb.n_owned + kXcds - 1u) / kXcds * kXcds * (ms ? 4u : 2u);
+    const uint32_t grid = n_parts;
+    const uint32_t tables = std::max(std::min(fc.n_lights, kMaxLights), 1u) * (uint32_t)sizeof(ShadeLight);
+    const bool plain = !ms && !sh;
+    const unsigned pad = lds_env >= 0 ? (unsigned)lds_env : (plain ? 1024u : 0u);
+    const unsigned lds = tables + pad;
+    if (ms) {
+        if (sh) hipLaunchKernelGGL((fb.clip ? k_shade<true, 4, true> : k_shade<true, 4, false>), dim3(grid), dim3(256), lds, stream, fb, n_parts);
+        else hipLaunchKernelGGL((fb.clip ? k_shade<false, 4, true> : k_shade<false, 4, false>), dim3(grid), dim3(256), lds, stream, fb, n_parts);
     } else {
-        if (sh) hipLaunchKernelGGL((fb.clip ? k_shade<1, true, 1, true> : k_shade<1, true, 1, false>), dim3(fb.n_owned * 4), dim3(256), pad, stream, fb);
-        else hipLaunchKernelGGL((fb.clip ? k_shade<1, false, 1, true> : k_shade<1, false, 1, false>), dim3(fb.n_owned * 4), dim3(256), pad, stream, fb);
+        if (sh) hipLaunchKernelGGL((fb.clip ? k_shade<true, 1, true> : k_shade<true, 1, false>), dim3(grid), dim3(256), lds, stream, fb, n_parts);
+        else hipLaunchKernelGGL((fb.clip ? k_shade<false, 1, true> : k_shade<false, 1, false>), dim3(grid), dim3(256), lds, stream, fb, n_parts);
     }
 }
 void launch_extract(const uint64_t* vis, const TileRef* order, uint32_t n_owned, const FrameConst& fc, float* depth,

@@ -132,6 +132,7 @@ VisualServer::~VisualServer() {
     try { comm_destroy(); } catch (...) {}
     if (geo_stream_) (void)hipStreamSynchronize(geo_stream_);
     if (stream_) (void)hipStreamSynchronize(stream_);
+    shade_profile_dump();
     for (CachedGraph& g : graphs_)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (auto& kv : meshes_)
@@ -935,6 +936,8 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     fb.wide_list = bp.wide_list; fb.tile_slices = bp.tile_slices; fb.raster_extra = bp.raster_extra;
     fb.entries = bp.entries; fb.counters = bp.counters;
     fb.launch_order = d_launch_order_.ptr; fb.n_owned = n_owned_;
+    fb.dims = ShadeDims{fc.n_lights, fc.n_items, fc.width, fc.height, fc.tiles_x,
+                        fc.tiles_x > 1u ? (uint32_t)((1ull << 32) / fc.tiles_x) + 1u : 0u, fc.rank, fc.world};
     fb.vis = bp.vis;
     fb.vis_stride = (uint64_t)tiles_x_ * tiles_y_ * kTilePixels;
     fb.frame_rgba8 = (world_ > 1 || scaled()) ? nullptr : (noalloc ? noalloc_out : d_frame_.ptr);
