@@ -70,10 +70,13 @@ pub struct rnd_frame_stats {
     pub n_setup: u64,
     pub n_bin_entries: u64,
     pub n_pixels: u64,
+    pub n_fragments: u64,
     pub n_draw_items: u32,
     pub n_lights: u32,
     pub n_tiles: u32,
     pub overflow: u32,
+    pub early_depth: u32,
+    pub reserved: u32,
 }
 
 extern "C" {

@@ -202,7 +202,8 @@ struct FrameCounters {
     uint32_t all_verts;        // a surviving unit uses a wide vertex range: transform every vertex block
     uint32_t n_wide;           // records on the wide list (not binned: every tile's raster workgroup checks them)
     uint32_t n_extra;          // (tile, slice) work items of heavy tiles beyond their first raster workgroup
-    uint32_t pad[3];
+    uint32_t n_fragments;      // covered samples k_setup's direct path resolved (saturating; summed by k_scan_tiles)
+    uint32_t pad[2];
 };
 
 // What the frame's shading kernel reports to the host through mapped pinned memory, so that the host learns of an
@@ -210,7 +211,8 @@ struct FrameCounters {
 // written last (after a system-scope fence); a report belongs to the frame whose tag it carries.
 struct FrameReport {
     uint32_t overflow, n_records, n_clip, n_entries;
-    uint32_t pad[3];
+    uint32_t n_fragments;      // the main pass's FrameCounters::n_fragments: depth complexity = n_fragments / (pixels * samples)
+    uint32_t pad[2];
     uint32_t frame_tag;
 };
 static_assert(sizeof(FrameReport) == 32, "FrameReport layout");

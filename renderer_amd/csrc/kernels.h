@@ -32,7 +32,7 @@ struct FrameBuffers {
     const float* srgb_lut;          // 512 entries: [0,256) sRGB8 -> linear, [256,512) alpha8 -> [0,1]
     uint32_t alpha_test;            // some draw item has kItemAlphaTest: launch the raster variants with the test
     uint32_t has_textures;          // some draw item is textured: launch the full shading variant
-    const uint32_t* unit_bases;     // n_items + 1: first work unit of each item
+    const uint32_t* unit_bases;     // n_items + 1 ascending first work units of the items' ranges in processing order, then the n_items draw items of those ranges
     uint2* active_units;            // (item, chunk) of the work units that survived k_cull
     uint32_t* vblock_needed;        // per kVertexBlock block of the frame's vertex slots: used by a surviving unit
     // geometry stage
@@ -51,6 +51,11 @@ struct FrameBuffers {
     uint32_t* tile_cursor;          // per tile, fill cursor of the multi-tile records
     uint32_t* entries;              // bin entries: record slots, grouped by tile
     FrameCounters* counters;
+    const FrameCounters* main_counters;   // the main pass's counter set (k_shade reports its fragment count)
+    uint32_t early_z;               // launch the plain main pass's k_setup with the depth test before the atomic (frames with depth complexity)
+    uint32_t setup_pass;            // early_z: 0 = one pass over every unit; nonzero = two passes around k_hiz (launch_setup sets 1 and 2)
+    uint32_t split_units;           // early_z, two passes: units numbered below this (the nearest draw items) form pass 1
+    float* hiz;                     // early_z, two passes: farthest depth per 8x8 pixel block, 16 per tile
     // the counter sets of all passes of the frame (shadow cascades, main pass, MSAA samples), read by the shading
     // kernel: a frame whose geometry overflowed an internal stream is not presented (the image keeps the previous
     // frame) and the host is told through `report`

@@ -22,9 +22,6 @@
 
 #include "kernels.h"
 
-#ifndef RND_EARLY_Z
-#define RND_EARLY_Z 0
-#endif
 
 namespace rnd {
 
@@ -220,7 +217,9 @@ __global__ __launch_bounds__(256) void k_cull(FrameBuffers fb) {
     const uint32_t view = gu / per_view, u = gu - view * per_view;
     const uint32_t n_vblocks = (fc.n_verts + kVertexBlock - 1) / kVertexBlock;
     if (gu < fc.n_units && ((fc.view_mask >> view) & 1u)) {
-        it = find_item(fb.unit_bases, fc.n_items, u);
+        // (ranges of units are numbered in processing order — near items first in frames with depth complexity —,
+        // the draw item of range k follows the n_items + 1 bases)
+        it = fb.unit_bases[fc.n_items + 1u + find_item(fb.unit_bases, fc.n_items, u)];
         const DrawItem& d = fb.items[it];
         chunk = u - d.unit_base;
         const uint32_t flags = d.flags;
@@ -576,7 +575,15 @@ __device__ __forceinline__ void pixel_samples(W w0, W w1, W w2, W b0, W b1, W b2
 
 // straight into the tile-major visibility buffer in HBM (no-return 64-bit min at the L2): the
 // path of the triangles that cover a handful of pixels, which never enter a bin
-struct GlobalSink {
+// kEarlyZ: the fragment is first compared with the word as a load sees it and only goes on to the atomic when it
+// would win.  The word only ever decreases, so a value read earlier can cause a redundant atomic, never a skipped one:
+// the result is the same bits.  The load is an agent-scope atomic load (served by the L2, where the atomics execute;
+// a line in the CU's own L1 could show the cleared word for as long as it stays there).  Frames with depth complexity
+// (fragments per pixel far above one: C4's ten layers) run this variant — there nine of ten fragments lose, and a
+// load is cheaper at the L2 than a 64-bit minimum; at one fragment per pixel the load is pure overhead (C3: +16 %),
+// which is why it is a compile-time variant and not a branch.
+template <bool kEarlyZ>
+struct GlobalSinkT {
     unsigned long long* vis;
     uint32_t tiles_x, rank, world;
     uint32_t plane_stride;              // words between the planes of consecutive MSAA samples
@@ -589,15 +596,14 @@ struct GlobalSink {
             // (kMaxRenderSize), and the address is then one scalar base + one vector offset
             const uint32_t at = smp * plane_stride + (ty * tiles_x + tx) * kTilePixels + (((uint32_t)j % kTile) * kTile + ((uint32_t)i % kTile));
             unsigned long long* const word = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(vis) + (at << 3));
-#if RND_EARLY_Z
-            // early test with a plain (possibly stale) load: the word only ever decreases, so a stale
-            // value can cause a redundant atomic, never a skipped one
-            if (!(key < *word)) return;
-#endif
+            if constexpr (kEarlyZ) {
+                if (!(key < __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return;
+            }
             __hip_atomic_fetch_min(word, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 };
+typedef GlobalSinkT<false> GlobalSink;
 
 template <bool kAlpha, int kSamples, class Sink>
 __device__ __forceinline__ void raster_small(const SetupRecord& r, int32_t i0, int32_t i1, int32_t j0, int32_t j1,
@@ -835,11 +841,12 @@ __device__ __forceinline__ void direct_pixel(const DirectTri& d, uint32_t k, con
 // kSamples: 1, or 4 (MSAA): every candidate pixel is tested at its four sample positions, one visibility plane each
 // kViews: the pass has several views (a light's shadow cascades), the unit names its view; the single-view
 // instantiation is the frame's main pass with the view's terms folded away
-template <bool kAlpha, int kSamples, bool kViews>
+// kEarlyZ: the direct path's fragments are compared with the visibility word before the atomic (GlobalSinkT)
+template <bool kAlpha, int kSamples, bool kViews, bool kEarlyZ>
 __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) {
     FrameConstRef fc = frame_const_ref(fb.frame_const);
     __shared__ uint32_t s_used;         // record slots of this workgroup's chunk handed out so far
-    __shared__ uint32_t s_valid[4];
+    __shared__ uint32_t s_valid[4], s_frags[4];
     __shared__ uint4 s_direct[4][64][5];   // per wave: the compacted small triangles of one iteration
     // Workgroups go to the eight XCDs round-robin (workgroup b to XCD b % 8), and each XCD has its own L2.  Units
     // next to each other in the list share vertices (the neighbouring rows of a mesh lie a few chunks apart), so
@@ -859,6 +866,15 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
     __syncthreads();
     typedef const __attribute__((address_space(4))) DrawItem* cptr_item;
     cptr_item d = (cptr_item)fb.items + item_s;
+    const uint32_t setup_pass = kEarlyZ ? fb.setup_pass : 0u;
+    if constexpr (kEarlyZ) {
+        // Two passes in frames with depth complexity: the units of the nearest draw items (numbered first: the host
+        // orders the items near to far) in pass 1, then k_hiz takes the farthest depth of every 8x8 pixel block, and
+        // pass 2 drops a small triangle whose nearest vertex lies behind everything in the blocks of its bbox before any
+        // pixel work.  Pass 0: every unit at once, per-fragment depth test only.
+        const bool near_item = d->unit_base < fb.split_units;
+        if ((setup_pass == 1u && !near_item) || (setup_pass == 2u && near_item)) return;      // (uniform over the workgroup)
+    }
     const uint32_t chunk_tris = fc.chunk_tris;
     const uint32_t first_t = chunk_s * chunk_tris;                         // first triangle of the chunk within its item
     const uint32_t item_tris = d->n_tris;
@@ -869,14 +885,15 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
     const bool tables_ok = guard(vb + nv <= fc.n_verts, fb.counters, kGuardSetup);
     const uint32_t chunk_base = unit_index * chunk_tris;
     const uint32_t n_tiles = fc.tiles_x * fc.tiles_y;
-    const GlobalSink direct_sink{reinterpret_cast<unsigned long long*>(fb.vis), fc.tiles_x, fc.rank, fc.world, (uint32_t)fb.vis_stride};
-    uint32_t valid = 0;
+    const GlobalSinkT<kEarlyZ> direct_sink{reinterpret_cast<unsigned long long*>(fb.vis), fc.tiles_x, fc.rank, fc.world, (uint32_t)fb.vis_stride};
+    uint32_t valid = 0, frags = 0;      // (frags: per lane, summed at the end)
     // (a unit without triangles or with tables that do not fit runs no iteration; the loads below need nv >= 1)
     const uint32_t n_iters = (tables_ok && nv != 0u) ? (n_here + 255u) / 256u : 0u;
     for (uint32_t iter = 0; iter < n_iters; ++iter) {
         const uint32_t local = iter * 256u + threadIdx.x;
         const uint32_t gid = tri_base + first_t + local;                   // draw-order triangle id
         bool emit = false, need_clip = false;
+        float z_near = 0.0f;
         SetupRecord rec;
         TileRect tr;
         {
@@ -908,6 +925,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
             }
             setup_triangle(in && idx_ok, v0, v1, v2, gid, fc, j_lo, j_hi, rec, tr, emit, need_clip);
             if (alpha_item) rec.flags |= 2u;
+            if constexpr (kEarlyZ) z_near = fminf(v0.z, fminf(v1.z, v2.z));
         }
         // queue the triangles that need the clipper (wave-compacted, rare)
         unsigned long long cm = __ballot(need_clip);
@@ -923,8 +941,29 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
         }
         valid += (uint32_t)__popcll(__ballot(emit));
         // small triangles: rasterize now, no record
-        const bool direct = emit && (rec.flags & 1u) &&
-                            (uint32_t)(tr.i1 - tr.i0 + 1) * (uint32_t)(tr.j1 - tr.j0 + 1) <= fb.direct_pixels;
+        const uint32_t box_px = (uint32_t)(tr.i1 - tr.i0 + 1) * (uint32_t)(tr.j1 - tr.j0 + 1);
+        bool direct = emit && (rec.flags & 1u) && box_px <= fb.direct_pixels;
+#ifndef RND_NO_FRAG_COUNT
+        // (pixel centres in the bboxes of the small triangles, whatever becomes of them: the host's measure of depth complexity)
+        frags += direct ? box_px : 0u;
+#endif
+        if constexpr (kEarlyZ) {
+            if (setup_pass == 2u) {
+                // Occluded as a whole?  The depth of every sample of the triangle is at least its nearest vertex's up to the
+                // rounding of the plane's evaluation (below 1e-6); if that, less a margin, is still behind the farthest depth
+                // k_hiz found in every 8x8 block the bbox touches (depths only decrease afterwards), no sample can win.
+                const uint32_t bx0 = (uint32_t)tr.i0 >> 3, bx1 = (uint32_t)tr.i1 >> 3, by0 = (uint32_t)tr.j0 >> 3, by1 = (uint32_t)tr.j1 >> 3;
+                bool occluded = direct && (bx1 - bx0 + 1u) * (by1 - by0 + 1u) <= 4u;      // (a bbox of at most 32 pixels spans more only as a thin strip)
+                if (occluded) {
+                    float farthest = 0.0f;
+                    for (uint32_t by = by0; by <= by1; ++by)
+                        for (uint32_t bx = bx0; bx <= bx1; ++bx)
+                            farthest = fmaxf(farthest, fb.hiz[((by >> 2) * fc.tiles_x + (bx >> 2)) * 16u + ((by & 3u) * 4u + (bx & 3u))]);
+                    occluded = z_near - 2.0e-6f > farthest;
+                }
+                if (occluded) { direct = false; emit = false; }
+            }
+        }
         // The wave's direct triangles are compacted into LDS and re-dealt 2, 4 or 8 lanes each, by the size of the
         // wave's bboxes: a pass costs its entry fetch plus one round per ceil(pixels / lanes) of its largest bbox, so
         // sub-pixel triangles (C3, C5: one or two pixel centres per bbox) want many triangles per pass and ~20-pixel
@@ -999,12 +1038,46 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
             fb.tilewords[slot] = make_uint2(pack_tileword(tr), pos);
         }
     }
-    if (lane == 0) s_valid[wave] = valid;
+    // bbox pixels of the direct path's triangles (the host reads depth complexity off their sum: FrameReport::n_fragments)
+    for (int o = 32; o > 0; o >>= 1) frags += __shfl_xor(frags, o);
+    if (lane == 0) { s_valid[wave] = valid; s_frags[wave] = frags; }
     __syncthreads();
     if (threadIdx.x == 0) {
         fb.chunk_count[unit_index] = s_used;
         fb.chunk_count[fc.n_units + unit_index] = s_valid[0] + s_valid[1] + s_valid[2] + s_valid[3];
+        fb.chunk_count[2u * fc.n_units + unit_index] = s_frags[0] + s_frags[1] + s_frags[2] + s_frags[3];
     }
+}
+
+// Farthest depth of every 8x8 pixel block of the frame, from the visibility words as they stand between the two
+// passes of k_setup's early-depth variant: 16 floats per 32x32 tile (block (bx, by) of the tile at by * 4 + bx).
+// One workgroup per tile of the frame; a tile this context does not own (sort-first) reads as 1.0: nothing is
+// dropped against it.  Depth bits of [0, 1] order as unsigned integers.
+__global__ __launch_bounds__(256) void k_hiz(FrameBuffers fb) {
+    FrameConstRef fc = frame_const_ref(fb.frame_const);
+    __shared__ uint32_t s_part[4][16];
+    const uint32_t tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tx = tile % fc.tiles_x, ty = tile / fc.tiles_x;
+    if (!owns_tile(tx, ty, fc.rank, fc.world)) {
+        if (tid < 16u) fb.hiz[tile * 16u + tid] = 1.0f;
+        return;
+    }
+    const unsigned long long* vis = reinterpret_cast<const unsigned long long*>(fb.vis) + (size_t)tile * kTilePixels;
+    // thread tid holds column tid % 32 of rows tid / 32 + 8 k: block column (tid % 32) / 8 of block row k
+    uint32_t m[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) m[k] = (uint32_t)(vis[k * 256u + tid] >> 32);
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        // the wave holds two rows of 32 columns: the 8 columns of a block (lanes xor 1, 2, 4), then the two rows (xor 32)
+        for (int o : {1, 2, 4, 32}) m[k] = max(m[k], (uint32_t)__shfl_xor((int)m[k], o));
+    }
+    if ((lane & 39u) == 0u) {            // lanes 0, 8, 16, 24: one per block column
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) s_part[wave][k * 4u + (lane >> 3)] = m[k];
+    }
+    __syncthreads();
+    if (tid < 16u) fb.hiz[tile * 16u + tid] = __uint_as_float(max(max(s_part[0][tid], s_part[1][tid]), max(s_part[2][tid], s_part[3][tid])));
 }
 
 // --- clipper (rare path): near, far and the four guard-band planes, then a fan -------------
@@ -1118,16 +1191,18 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(FrameBuffers fb, Capacities
     const uint32_t n_active = min(fb.counters->n_active, fc.n_units);
     const uint32_t n_wide = min(fb.counters->n_wide, cap.wide_list);
     uint32_t v = 0, used = 0;
+    unsigned long long fr = 0;          // covered samples of the direct path (depth complexity, for the host)
     for (uint32_t c0 = 0; c0 < n_active; c0 += 8u * 1024u) {
-        uint32_t part[8], slots[8];
+        uint32_t part[8], slots[8], frags[8];
 #pragma unroll
         for (uint32_t k = 0; k < 8; ++k) {          // independent loads in flight, not a chain of round trips
             const uint32_t c = c0 + k * 1024u + tid;
             part[k] = c < n_active ? fb.chunk_count[fc.n_units + c] : 0u;
             slots[k] = c < n_active ? fb.chunk_count[c] : 0u;
+            frags[k] = c < n_active ? fb.chunk_count[2u * fc.n_units + c] : 0u;
         }
 #pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) { v += part[k]; used |= slots[k]; }
+        for (uint32_t k = 0; k < 8; ++k) { v += part[k]; used |= slots[k]; fr += frags[k]; }
     }
     // A pass in which no unit wrote a record and the clipper wrote none either (every triangle took k_setup's direct path:
     // C3, C5, the depth-only passes of such scenes) has no tile counts to scan: k_bin_fill and k_raster look at
@@ -1198,14 +1273,17 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(FrameBuffers fb, Capacities
         carry = s_batch_total;
         __syncthreads();
     }
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if (lane == 0) s_valid[wave] = v;
+    for (int o = 32; o > 0; o >>= 1) { v += __shfl_xor(v, o); fr += __shfl_xor(fr, o); }
+    __shared__ unsigned long long s_frags[16];
+    if (lane == 0) { s_valid[wave] = v; s_frags[wave] = fr; }
     __syncthreads();
     if (tid == 1023) {
         const uint32_t n_entries = carry;
         uint32_t total = 0;
-        for (uint32_t w = 0; w < 16; ++w) total += s_valid[w];
+        unsigned long long frags_total = 0;
+        for (uint32_t w = 0; w < 16; ++w) { total += s_valid[w]; frags_total += s_frags[w]; }
         atomicAdd(&fb.counters->n_valid, total);
+        fb.counters->n_fragments = (uint32_t)min(frags_total, 0xFFFFFFFFull);
         fb.counters->n_entries = n_entries;
         if (n_entries > cap.entries) atomicOr(&fb.counters->overflow, 4u);
     }
@@ -2154,6 +2232,7 @@ __global__ __launch_bounds__(256, kShadows ? (kSamples > 1 ? 1 : 5) : (kSamples 
         if (blockIdx.x == 0 && tid == 0 && fb.report) {
             volatile FrameReport* r = fb.report;
             r->overflow = ovf; r->n_records = n_rec; r->n_clip = n_clip; r->n_entries = n_ent;
+            r->n_fragments = ((cptr_counters)fb.main_counters)->n_fragments;      // (the main pass's: the host picks its k_setup variant by it)
             __threadfence_system();
             r->frame_tag = fb.report_tag;
         }
@@ -2751,18 +2830,30 @@ void launch_setup(const FrameBuffers& fb, const FrameConst& fc, const Capacities
     // (experiment aid: unused dynamic LDS per workgroup lowers the occupancy of the main pass's setup kernel)
     static const unsigned lds_pad = [] { const char* e = getenv("RND_SETUP_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
     if (lds_pad && fc.n_views <= 1u && !fb.alpha_test && !ms) {
-        hipLaunchKernelGGL((k_setup<false, 1, false>), grid, dim3(256), lds_pad, stream, fb, cap);
+        hipLaunchKernelGGL((k_setup<false, 1, false, false>), grid, dim3(256), lds_pad, stream, fb, cap);
         return;
     }
     if (fc.n_views > 1u) {
         // a light's cascades: depth only (no alpha test, one sample; visual_server.cpp builds them so)
-        hipLaunchKernelGGL((k_setup<false, 1, true>), grid, dim3(256), 0, stream, fb, cap);
+        hipLaunchKernelGGL((k_setup<false, 1, true, false>), grid, dim3(256), 0, stream, fb, cap);
     } else if (fb.alpha_test) {
-        if (ms) hipLaunchKernelGGL((k_setup<true, 4, false>), grid, dim3(256), 0, stream, fb, cap);
-        else hipLaunchKernelGGL((k_setup<true, 1, false>), grid, dim3(256), 0, stream, fb, cap);
+        if (ms) hipLaunchKernelGGL((k_setup<true, 4, false, false>), grid, dim3(256), 0, stream, fb, cap);
+        else hipLaunchKernelGGL((k_setup<true, 1, false, false>), grid, dim3(256), 0, stream, fb, cap);
     } else {
-        if (ms) hipLaunchKernelGGL((k_setup<false, 4, false>), grid, dim3(256), 0, stream, fb, cap);
-        else hipLaunchKernelGGL((k_setup<false, 1, false>), grid, dim3(256), 0, stream, fb, cap);
+        // (the early-depth variant exists for the plain main pass only: the frames it is for are that)
+        if (ms) hipLaunchKernelGGL((k_setup<false, 4, false, false>), grid, dim3(256), 0, stream, fb, cap);
+        else if (fb.early_z) {
+            if (fb.setup_pass == 0u) hipLaunchKernelGGL((k_setup<false, 1, false, true>), grid, dim3(256), 0, stream, fb, cap);
+            else {
+                FrameBuffers pass = fb;
+                pass.setup_pass = 1u;
+                hipLaunchKernelGGL((k_setup<false, 1, false, true>), grid, dim3(256), 0, stream, pass, cap);
+                hipLaunchKernelGGL(k_hiz, dim3(fc.tiles_x * fc.tiles_y), dim3(256), 0, stream, fb);
+                pass.setup_pass = 2u;
+                hipLaunchKernelGGL((k_setup<false, 1, false, true>), grid, dim3(256), 0, stream, pass, cap);
+            }
+        }
+        else hipLaunchKernelGGL((k_setup<false, 1, false, false>), grid, dim3(256), 0, stream, fb, cap);
     }
 }
 void launch_clip(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {

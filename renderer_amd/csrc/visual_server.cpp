@@ -138,7 +138,7 @@ VisualServer::~VisualServer() {
     for (auto& kv : meshes_)
         for (auto& s : kv.second.submeshes) { s.vertex_buffer.release(); s.positions.release(); s.index_buffer.release(); s.chunks.release(); }
     for (int k = 0; k < 2; ++k) { d_tables_[k].release(); d_clip_[k].release(); d_vis_[k].release(); d_counters_[k].release(); }
-    d_snap_.release(); d_wide_list_.release(); d_tile_slices_.release(); d_raster_extra_.release();
+    d_snap_.release(); d_hiz_.release(); d_wide_list_.release(); d_tile_slices_.release(); d_raster_extra_.release();
     d_records_.release(); d_tilewords_.release(); d_clip_queue_.release(); d_chunk_count_.release(); d_vblock_needed_.release(); d_active_units_.release(); d_tile_count_.release();
     d_tile_offset_.release(); d_tile_cursor_.release(); d_entries_.release();
     for (auto& kv : textures_) kv.second.texels.release();
@@ -503,7 +503,7 @@ void VisualServer::build_frame(std::vector<DrawItem>& items, std::vector<uint32_
     bool any_directional = false;
     for (const RenderLight& l : lights_) any_directional = any_directional || l.light.kind == RND_LIGHT_DIRECTIONAL;
     const size_t expect = mesh_instances_.size() + 8;
-    items.reserve(expect); vert_bases.reserve(expect + 1); tri_bases.reserve(expect + 1); unit_bases.reserve(expect + 1);
+    items.reserve(expect); vert_bases.reserve(expect + 1); tri_bases.reserve(expect + 1);
     if (any_directional) shadow_items.reserve(expect);
     // for mesh_instance { for submesh } — visual_server.rs:227-245
     for (const RenderMeshInstance& inst : mesh_instances_) {
@@ -548,10 +548,9 @@ void VisualServer::build_frame(std::vector<DrawItem>& items, std::vector<uint32_
                 if (!tex->second.opaque && !(d.flags & kItemSkip)) { d.flags |= kItemAlphaTest; frame_alpha_test_ = true; }
             }
             // small chunks until the frame turns out to be a large one (patched below)
-            d.chunks = s.chunks.ptr; d.n_chunks = s.n_chunks_small; d.unit_base = (uint32_t)unit_base;
+            d.chunks = s.chunks.ptr; d.n_chunks = s.n_chunks_small; d.unit_base = 0;       // (units are numbered below)
             vert_bases.push_back(d.vert_base);
             tri_bases.push_back(d.tri_base);
-            unit_bases.push_back(d.unit_base);
             vert_base += d.n_verts; tri_base += d.n_tris; unit_base += d.n_chunks;
             if (vert_base >= 0xFFFFFFFFull || tri_base >= 0xFFFFFFFFull || unit_base * kChunkTrisSmall >= 0xFFFFFFF0ull) throw Error(RND_ERR_INVALID, "frame exceeds 2^32 vertices or triangles");
             items.push_back(d);
@@ -573,18 +572,54 @@ void VisualServer::build_frame(std::vector<DrawItem>& items, std::vector<uint32_
     if (tri_base > small_frame_tris) {
         // a large frame: the large chunks of every submesh (they follow the small ones in its table)
         fc_.chunk_tris = kChunkTris;
-        unit_base = 0;
-        for (size_t k = 0; k < items.size(); ++k) {
-            DrawItem& d = items[k];
-            d.chunks += d.n_chunks;
-            d.n_chunks = (d.n_tris + kChunkTris - 1) / kChunkTris;
-            d.unit_base = unit_bases[k] = (uint32_t)unit_base;
-            if (any_directional) { DrawItem& sd = shadow_items[k]; sd.chunks = d.chunks; sd.n_chunks = d.n_chunks; sd.unit_base = d.unit_base; }
-            unit_base += d.n_chunks;
-        }
-        if (unit_base * kChunkTris >= 0xFFFFFFF0ull) throw Error(RND_ERR_INVALID, "frame exceeds 2^32 record slots");
+        for (DrawItem& d : items) { d.chunks += d.n_chunks; d.n_chunks = (d.n_tris + kChunkTris - 1) / kChunkTris; }
     }
-    unit_bases.push_back((uint32_t)unit_base);
+    // Work units are numbered item by item in PROCESSING order, which is draw order except in frames with depth
+    // complexity (early_z_frame_): there the items go near to far (nearest view depth of the item's box), so that the
+    // depth test in front of the visibility atomics (k_setup's early-depth variant) finds the near surfaces already
+    // resolved when the far ones arrive.  Triangle ids — and with them every tie — stay in draw order.
+    const size_t n_items = items.size();
+    std::vector<uint32_t>& order = unit_order_;
+    order.resize(n_items);
+    for (size_t k = 0; k < n_items; ++k) order[k] = (uint32_t)k;
+    if (early_z_frame_ && n_items > 1) {
+        std::vector<float>& key = unit_order_key_;
+        key.resize(n_items);
+        size_t k = 0;
+        for (const RenderMeshInstance& inst : mesh_instances_) {
+            const RenderMesh& mesh = meshes_.at(inst.mesh);
+            for (const RenderSubmesh& sub : mesh.submeshes) {
+                float nearest = std::numeric_limits<float>::infinity();
+                for (int c = 0; c < 8; ++c) {
+                    const Vec4 p{(c & 1) ? sub.box_hi[0] : sub.box_lo[0], (c & 2) ? sub.box_hi[1] : sub.box_lo[1], (c & 4) ? sub.box_hi[2] : sub.box_lo[2], 1.0f};
+                    const Vec4 v = transform(view_, transform(inst.transform, p));
+                    nearest = std::isfinite(v.z) ? std::min(nearest, v.z) : -std::numeric_limits<float>::infinity();
+                }
+                key[k++] = nearest;
+            }
+        }
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+    }
+    unit_bases.resize(2 * n_items + 1);
+    unit_base = 0;
+    for (size_t k = 0; k < n_items; ++k) {
+        DrawItem& d = items[order[k]];
+        d.unit_base = unit_bases[k] = (uint32_t)unit_base;
+        unit_bases[n_items + 1 + k] = order[k];
+        unit_base += d.n_chunks;
+    }
+    if (unit_base * fc_.chunk_tris >= 0xFFFFFFF0ull) throw Error(RND_ERR_INVALID, "frame exceeds 2^32 record slots");
+    unit_bases[n_items] = (uint32_t)unit_base;
+    // the early-depth variant's first pass: the nearest items, up to a tenth of the frame's units (at least one item)
+    split_units_ = 0;
+    if (early_z_frame_ && n_items > 1) {
+        for (size_t k = 0; k + 1 < n_items; ++k) {
+            split_units_ = unit_bases[k + 1];
+            if ((uint64_t)split_units_ * 10u >= unit_base) break;
+        }
+    }
+    if (any_directional)
+        for (size_t k = 0; k < n_items; ++k) { DrawItem& sd = shadow_items[k]; const DrawItem& d = items[k]; sd.chunks = d.chunks; sd.n_chunks = d.n_chunks; sd.unit_base = d.unit_base; }
     fc_.n_units = (uint32_t)unit_base;
     for (const RenderLight& l : lights_) {
         GpuLight g{};
@@ -704,6 +739,10 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     std::vector<GpuLight>& lights = gpu_lights_;
     std::vector<DrawItem>& shadow_items = shadow_items_;
     items.clear(); vert_bases.clear(); tri_bases.clear(); unit_bases.clear(); lights.clear(); shadow_items.clear();
+    {
+        const char* const e = std::getenv("RND_EARLY_DEPTH");
+        early_z_frame_ = e && *e ? std::atoi(e) != 0 : early_z_state_;
+    }
     build_frame(items, vert_bases, tri_bases, unit_bases, lights, shadow_items);
     // every directional light owns a cascade set (the reference also fills maps for point lights,
     // which its shader never reads: visual_server.rs:358-436, render_mesh.wgsl:150-152)
@@ -772,10 +811,11 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     struct {
         float4* clip; SnapVert* snap; SetupRecord* records; uint32_t *tilewords, *clip_queue, *chunk_count, *active_units, *vblock_needed, *entries,
             *wide_list, *tile_slices, *tile_count, *tile_offset, *tile_cursor;
-        uint2* raster_extra; FrameCounters* counters; uint64_t* vis;
+        uint2* raster_extra; FrameCounters* counters; uint64_t* vis; float* hiz;
     } bp{};
     const size_t n_vblocks = ((size_t)fc.n_verts / kVertexBlock + 2) * n_views_max;
     const size_t n_unit_words = std::max<size_t>(2 * (size_t)fc.n_units * n_views_max, 2);
+    const size_t n_count_words = std::max<size_t>(3 * (size_t)fc.n_units * n_views_max, 3);      // per unit: record slots used, triangles that survived, covered samples
     const size_t n_view_verts = std::max<size_t>((size_t)fc.n_verts * n_views_max, 1);
     // Whether K1 keeps the clip positions for the shading kernel or that kernel makes them again from the corners' vertices
     // (kernels.hip, corner_clip: the same bits either way).  Storing costs K1 16 of its 44 bytes per vertex (1.45 us per
@@ -792,7 +832,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         bp.clip = store_clip && store_clip_fits ? arena.take<float4>(std::max<size_t>(fc.n_verts, 1)) : nullptr; bp.snap = arena.take<SnapVert>(n_view_verts);
         bp.records = arena.take<SetupRecord>(cap_.records); bp.tilewords = arena.take<uint32_t>(2 * (size_t)cap_.records);
         bp.clip_queue = arena.take<uint32_t>(2 * (size_t)cap_.clip_queue);      // triangle ids, then their views
-        bp.chunk_count = arena.take<uint32_t>(n_unit_words);
+        bp.chunk_count = arena.take<uint32_t>(n_count_words);
         bp.active_units = arena.take<uint32_t>(n_unit_words);
         bp.vblock_needed = arena.take<uint32_t>(n_vblocks);
         bp.entries = arena.take<uint32_t>(cap_.entries);
@@ -802,12 +842,13 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         bp.tile_count = arena.take<uint32_t>(2 * n_tiles); bp.tile_offset = arena.take<uint32_t>(n_tiles); bp.tile_cursor = arena.take<uint32_t>(n_tiles);
         bp.counters = arena.take<FrameCounters>(n_counter_sets);
         bp.vis = arena.take<uint64_t>(n_tiles * kTilePixels * msaa_);
+        bp.hiz = early_z_frame_ ? arena.take<float>(n_tiles * 16) : nullptr;
     } else {
         if (store_clip && store_clip_fits) d_clip_[p].ensure(std::max<size_t>(fc.n_verts, 1));        // (the main pass's only: shading reads it)
         d_snap_.ensure(n_view_verts);
         d_records_.ensure(cap_.records); d_tilewords_.ensure(2 * (size_t)cap_.records);
         d_clip_queue_.ensure(2 * (size_t)cap_.clip_queue);
-        d_chunk_count_.ensure(n_unit_words);
+        d_chunk_count_.ensure(n_count_words);
         d_active_units_.ensure(n_unit_words);
         d_vblock_needed_.ensure(n_vblocks);
         d_entries_.ensure(cap_.entries);
@@ -822,6 +863,8 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         bp.wide_list = d_wide_list_.ptr; bp.tile_slices = d_tile_slices_.ptr; bp.raster_extra = d_raster_extra_.ptr;
         bp.tile_count = d_tile_count_.ptr; bp.tile_offset = d_tile_offset_.ptr; bp.tile_cursor = d_tile_cursor_.ptr;
         bp.counters = d_counters_[p].ptr; bp.vis = d_vis_[p].ptr;
+        if (early_z_frame_) d_hiz_.ensure(n_tiles * 16);
+        bp.hiz = d_hiz_.ptr;
     }
 
     // stage the per-frame tables in pinned memory and upload them
@@ -934,7 +977,11 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     fb.unit_bases = reinterpret_cast<const uint32_t*>(tb + off_ub); fb.active_units = reinterpret_cast<uint2*>(bp.active_units); fb.vblock_needed = bp.vblock_needed;
     fb.tile_count = bp.tile_count; fb.tile_offset = bp.tile_offset; fb.tile_cursor = bp.tile_cursor;
     fb.wide_list = bp.wide_list; fb.tile_slices = bp.tile_slices; fb.raster_extra = bp.raster_extra;
-    fb.entries = bp.entries; fb.counters = bp.counters;
+    fb.entries = bp.entries; fb.counters = bp.counters; fb.main_counters = bp.counters;
+    fb.early_z = early_z_frame_ ? 1u : 0u;
+    fb.split_units = split_units_;
+    fb.setup_pass = early_z_frame_ && split_units_ != 0u && split_units_ < fc.n_units ? 1u : 0u;
+    fb.hiz = bp.hiz;
     fb.launch_order = d_launch_order_.ptr; fb.n_owned = n_owned_;
     fb.dims = ShadeDims{fc.n_lights, fc.n_items, fc.width, fc.height, fc.tiles_x,
                         fc.tiles_x > 1u ? (uint32_t)((1ull << 32) / fc.tiles_x) + 1u : 0u, fc.rank, fc.world};
@@ -1153,6 +1200,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     stats_ = rnd_frame_stats{};
     stats_.n_vertices = fc.n_verts; stats_.n_triangles = fc.n_tris; stats_.n_draw_items = fc.n_items;
     stats_.n_lights = fc.n_lights; stats_.n_tiles = n_owned_;
+    stats_.early_depth = early_z_frame_ && !frame_alpha_test_ && msaa_ == 1 ? 1u : 0u;
     stats_.n_pixels = 0;
 }
 
@@ -1164,6 +1212,14 @@ void VisualServer::render() {
         truncated_notice_ = false;
         throw Error(RND_ERR_TRUNCATED, "an earlier frame overflowed an internal stream and was not presented; the streams have been grown and this frame is enqueued");
     }
+}
+
+void VisualServer::note_depth_complexity(uint64_t n_fragments) {
+    // (n_fragments: pixel centres in the bboxes of the small triangles, about twice what they cover: C3 1.4 per pixel,
+    // C4 — ten layers — 30)
+    const double per_sample = (double)n_fragments / ((double)width_ * height_ * msaa_);
+    if (per_sample >= 6.0) early_z_state_ = true;
+    else if (per_sample < 4.0) early_z_state_ = false;
 }
 
 void VisualServer::grow_streams(uint32_t overflow, uint32_t n_records, uint32_t n_clip, uint32_t n_entries) {
@@ -1180,6 +1236,7 @@ void VisualServer::poll_reports() {
         const volatile FrameReport* r = &h_reports_[s];
         if (r->frame_tag != report_expect_[s]) continue;       // not there yet
         report_expect_[s] = 0;
+        note_depth_complexity(r->n_fragments);
         const uint32_t ovf = r->overflow & 7u;
         if (!ovf) continue;
         grow_streams(ovf, r->n_records, r->n_clip, r->n_entries);
@@ -1233,6 +1290,8 @@ void VisualServer::finish() {
     }
     const FrameCounters c = *h_counters_;
     stats_.n_setup = c.n_valid; stats_.n_bin_entries = c.n_entries; stats_.overflow = grew;
+    stats_.n_fragments = c.n_fragments;
+    note_depth_complexity(c.n_fragments);
     // pixels this context rasterizes: owned tiles clipped to the frame
     uint64_t px = 0;
     for (uint32_t t : owned_tiles(rank_, world_)) {

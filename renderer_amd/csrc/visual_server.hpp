@@ -319,6 +319,15 @@ private:
     // the per-frame host tables, kept between frames so that a steady state allocates nothing on the host either
     std::vector<DrawItem> items_, shadow_items_;
     std::vector<uint32_t> vert_bases_, tri_bases_, unit_bases_;
+    std::vector<uint32_t> unit_order_;          // draw items in processing order (build_frame)
+    std::vector<float> unit_order_key_;
+    // Depth complexity of the frames seen (bbox pixels of the small triangles per sample, from the frame reports): at 6
+    // and above the next frames run k_setup's early-depth variant with the items near to far, below 4 the plain one again.
+    // RND_EARLY_DEPTH = 0 / 1 forces one (read per frame).
+    bool early_z_state_ = false, early_z_frame_ = false;
+    uint32_t split_units_ = 0;                  // units of the early-depth variant's first pass (build_frame)
+    DeviceBuffer<float> d_hiz_;                 // farthest depth per 8x8 block between its two passes
+    void note_depth_complexity(uint64_t n_fragments);
     std::vector<GpuLight> gpu_lights_;
     std::vector<FrameConst> consts_;
 
