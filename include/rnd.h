@@ -108,7 +108,10 @@ typedef struct rnd_frame_stats {
 /* reference: VisualServer::new (visual_server.rs:55-154).  No window: width/height are the
  * surface size; `device` is the HIP device ordinal.  Defaults as the reference: render size
  * factor 1.0, MSAA 1, tone mapping Reinhard (:85-90), ambient (0.3,0.5,0.9,0.04) (:67),
- * default material white/lit (material.rs:10-19), unit quad mesh (:865-873). */
+ * default material white/lit (material.rs:10-19), unit quad mesh (:865-873).
+ * Limit the reference does not have: the render size (surface size, and surface size times the render size factor) is
+ * at most 8192 x 8192 pixels (tile coordinates are packed in 8 bits); larger sizes return RND_ERR_INVALID here and from
+ * rnd_set_render_size / rnd_set_render_size_factor. */
 int rnd_create(rnd_ctx** out, uint32_t width, uint32_t height, int device);
 void rnd_destroy(rnd_ctx* ctx);
 /* text of the last error on this context (or of the last failed rnd_create when ctx==NULL) */
@@ -159,7 +162,9 @@ int rnd_set_camera(rnd_ctx* ctx, const float transform_cols[16], float vfov, flo
  * radius is ignored for directional lights (Light::radius().unwrap_or_default()).
  * A directional light's four shadow cascades (compute_shadow_cascade_projviews :771-863) are
  * computed here, from the camera current at this call, as create_light/update_light do
- * (:380-381, :445-446); rnd_set_camera does not recompute them (:221). */
+ * (:380-381, :445-446); rnd_set_camera does not recompute them (:221).
+ * Limit the reference does not have: at most 256 lights per context (the reference's list is unbounded, :350-436);
+ * the 257th new id returns RND_ERR_INVALID. */
 int rnd_set_light(rnd_ctx* ctx, uint64_t id, const float transform_cols[16], const float color[4],
                   uint32_t kind, float radius);
 /* reference: set_mesh_instance(UniqueNodeId, Affine3A, Handle<Mesh>, &AssetServer) :481-506
@@ -229,8 +234,9 @@ int rnd_read_overlay_rgba8(rnd_ctx* ctx, uint8_t* dst);
  * until it is complete, so what they return is always a whole frame. */
 int rnd_render(rnd_ctx* ctx);
 int rnd_finish(rnd_ctx* ctx);
-/* The frame of rnd_render for callers that cannot allocate (code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same scene state, same kernels, same
+/* The frame of rnd_render for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc,
+ * code that prepares for a HIP graph capture; the call itself waits on events and is not to be made WHILE a stream is
+ * capturing).  No counterpart in the reference.  Same scene state, same kernels, same
  * pixels as rnd_render, but
  *  - the image goes to the caller's device buffer `out_rgba8_dev` (row-major width*height*4 bytes; on a tile
  *    partition the tile-major n_owned_tiles*tile_px*tile_px*4 bytes of rnd_tiles_device_ptr), and
@@ -245,8 +251,10 @@ int rnd_finish(rnd_ctx* ctx);
  * RND_ERR_OOM and the next frame is laid out with the capacities learnt.  Everything runs on the context's
  * stream, without the overlap with the previous frame.  All contexts on one GPU share the array and it keeps
  * the last frame's contents (what must start at zero is cleared by the frame's first kernel): frames through
- * this entry point must not overlap on one GPU — finish one (or order them on one stream) before the next —
- * and the read-backs of such a frame (rnd_read_depth / _coverage / _triangle_ids) must come before the next one. */
+ * this entry point must not overlap on one GPU.  A context that asks for the array while ANOTHER context's frame through
+ * this entry point is still in flight is refused with RND_ERR_INVALID (and left as it was: a refused frame changes no
+ * state); when it takes the array, the previous holder's frame is gone (its read-backs return RND_ERR_NO_FRAME).
+ * Frames of one context follow each other on its stream. */
 int rnd_render_noalloc(rnd_ctx* ctx, void* out_rgba8_dev, uint64_t out_bytes);
 
 /* ---- read-backs (what the reference shows on the surface / in its H/J/K debug views) -- */
@@ -321,11 +329,14 @@ int rnd_comm_init(rnd_ctx* ctx, const uint8_t id[RND_COMM_ID_BYTES], uint32_t ra
 int rnd_comm_destroy(rnd_ctx* ctx);
 /* Sort-first, collective (every rank calls it after rnd_render; the tile partition must be the communicator's rank and
  * world): every rank sends its tile-major buffer straight to rank 0, which scatters all of them into its row-major
- * frame (rnd_color_device_ptr / rnd_read_color_rgba8 there).  Stream-ordered on the context's stream. */
+ * frame (rnd_color_device_ptr / rnd_read_color_rgba8 there: until the next rnd_render, read-backs on rank 0 return the
+ * assembled frame).  The call first completes this rank's frame as rnd_finish does (a frame that overflowed an internal
+ * stream is re-run before its tiles leave); the exchange itself is stream-ordered on the context's stream. */
 int rnd_gather_tiles(rnd_ctx* ctx);
 /* Sort-last, collective (every rank calls it after rnd_render of its shard with the packed output on): direct-send
  * composite — the packed frame is cut into `world` strips, strip s of every rank goes to rank s, rank s takes the
- * minimum (rnd_min_packed), the finished strips go to rank 0, which unpacks them into its frame. */
+ * minimum (rnd_min_packed), the finished strips go to rank 0, which unpacks them into its frame (read-backs on rank 0
+ * return that frame until the next rnd_render).  Completes this rank's shard first, as rnd_gather_tiles does. */
 int rnd_composite_packed(rnd_ctx* ctx);
 /* Use the caller's HIP stream (hipStream_t as void*) for this context; NULL = own stream.  Shading, present,
  * the 2D overlay, read-backs, detile/unpack and everything the caller enqueues behind rnd_render are ordered

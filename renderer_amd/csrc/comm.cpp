@@ -98,6 +98,7 @@ void VisualServer::gather_tiles() {
     if (comm_world_ == 1) return;           // the frame is already whole and row-major
     if (!last_tiles_out_) throw Error(RND_ERR_NO_FRAME, "no frame rendered on the partition yet");
     use_device();
+    finish();            // a truncated frame is re-run here: its tiles must not leave as they are
     Rccl& r = rccl();
     ncclComm_t c = static_cast<ncclComm_t>(comm_);
     // every rank's share padded to the largest (rank 0's: stripes are dealt from rank 0)
@@ -116,6 +117,7 @@ void VisualServer::gather_tiles() {
         }
         NCCL_CHECK(r.GroupEnd());
         detile_gathered(comm_world_, all, stride);
+        assembled_frame_ = true;        // d_frame_ holds every rank's tiles: read-backs hand it out as it is
     } else if (mine) {
         NCCL_CHECK(r.GroupStart());
         NCCL_CHECK(r.Send(last_tiles_out_, mine, ncclUint8, 0, c, stream_));
@@ -128,6 +130,7 @@ void VisualServer::composite_packed() {
     if (!comm_) throw Error(RND_ERR_INVALID, "no communicator: call rnd_comm_init first");
     if (!want_packed_ || !last_packed_out_) throw Error(RND_ERR_NO_FRAME, "no packed frame: call rnd_packed_device_ptr once before rendering");
     use_device();
+    finish();            // (as gather_tiles: a truncated shard is re-run before it is composited)
     Rccl& r = rccl();
     ncclComm_t c = static_cast<ncclComm_t>(comm_);
     const uint32_t W = comm_world_, me = comm_rank_;
@@ -165,6 +168,7 @@ void VisualServer::composite_packed() {
         launch_unpack(done, fc, d_frame_.ptr, nullptr, stream_);
         last_frame_out_ = d_frame_.ptr;
         have_frame_ = true;
+        assembled_frame_ = true;
     }
     HIP_CHECK_COMM(hipGetLastError());
 }

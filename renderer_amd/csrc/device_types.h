@@ -177,6 +177,16 @@ struct Prim2D {
 };
 static_assert(sizeof(Prim2D) == 48, "Prim2D layout");
 
+struct FrameCounters;
+// The counter sets of a frame's passes, as the kernels behind the geometry phase look at them: a frame whose geometry
+// overflowed an internal stream is not presented — k_shade, k_present and k_overlay all leave the image alone.
+struct OverflowGate {
+    const FrameCounters* all_counters;
+    uint32_t n_counter_sets;
+    uint32_t pad;
+    uint64_t ran_mask;            // bit s: counter set s was written this frame (sets beyond 63: assumed)
+};
+
 struct OverlayParams {
     const Prim2D* prims;          // boxes first, then the glyphs of every text, in draw order
     const float* srgb_lut;        // 256 entries: sRGB8 -> linear
@@ -190,6 +200,7 @@ struct OverlayParams {
     uint32_t* frame;              // row-major surface RGBA8, or null on a tile partition
     uint32_t* tiles;              // this context's compact tile-major RGBA8 on a tile partition
     uint32_t* overlay_out;        // row-major surface-sized 2D target
+    OverflowGate gate;
 };
 
 struct FrameCounters {

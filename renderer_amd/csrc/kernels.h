@@ -107,7 +107,7 @@ void launch_detile_gathered(const uint8_t* gathered, uint64_t stride_bytes, uint
 // hdr (w x h, rgb f32 holding f16 values) sampled at the surface's pixel centres, nearest or
 // linear, then tone map + sRGB into the sw x sh RGBA8 frame
 void launch_present(const float* hdr, uint32_t w, uint32_t h, uint8_t* frame_rgba8, uint32_t sw, uint32_t sh,
-                    bool linear, uint32_t tone, hipStream_t stream);
+                    bool linear, uint32_t tone, const OverflowGate& gate, hipStream_t stream);
 // packed (depth | rgba8) row-major -> RGBA8 frame + tile-major vis depth
 // n_tiles = tiles of the surface (32x32); workgroups of tiles another rank owns return at once
 void launch_overlay(const OverlayParams& p, uint32_t n_tiles, hipStream_t stream);

@@ -42,9 +42,20 @@ __device__ __forceinline__ bool guard(bool ok, FrameCounters* counters, uint32_t
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
+// Whether any pass of the frame overflowed an internal stream (records, clip queue, bin entries): wave-uniform scalar loads.
+__device__ __forceinline__ bool frame_overflowed(const OverflowGate& g) {
+    typedef const __attribute__((address_space(4))) FrameCounters* cptr_counters;
+    uint32_t ovf = 0;
+    for (uint32_t s = 0; s < g.n_counter_sets; ++s) {
+        if (s < 64u && !((g.ran_mask >> s) & 1ull)) continue;
+        ovf |= ((cptr_counters)g.all_counters + s)->overflow;
+    }
+    return (ovf & 7u) != 0u;
+}
+
 // The frame's constants live in device memory (uploaded with the per-frame tables), not in the kernel
-// arguments: the arguments of a frame's kernels then only change when buffers or the scene's shape
-// do, so the launch sequence can be replayed as a HIP graph.  They are read through the constant
+// arguments (one upload per frame, small launch packets; the shading kernel alone takes the frame's shape by value:
+// FrameBuffers::dims).  They are read through the constant
 // address space — scalar loads the compiler may repeat or re-order like kernel arguments — field by
 // field where used (copying the struct up front kept all 70 dwords live: SGPR spills into VGPR lanes).
 typedef const __attribute__((address_space(4))) FrameConst& FrameConstRef;
@@ -2646,6 +2657,9 @@ __global__ __launch_bounds__(256) void k_overlay(OverlayParams p) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
     if (p.world > 1u && !owns_tile(tx, ty, p.rank, p.world)) return;
+    // a truncated frame was not shaded: the image still holds the frame before it WITH its overlay; blending again would
+    // composite translucent boxes and glyph edges twice
+    if (frame_overflowed(p.gate)) return;
     s_lut[tid] = p.srgb_lut[tid];
     const int32_t tile_x0 = (int32_t)(tx * kTile), tile_y0 = (int32_t)(ty * kTile);
     // sub-pixel bounds of the tile's pixel centres
@@ -2738,7 +2752,8 @@ __global__ __launch_bounds__(256) void k_overlay(OverlayParams p) {
 }
 
 __global__ void k_present(const float* __restrict__ hdr, uint32_t w, uint32_t h, uint32_t* __restrict__ frame,
-                          uint32_t sw, uint32_t sh, uint32_t linear, uint32_t tone) {
+                          uint32_t sw, uint32_t sh, uint32_t linear, uint32_t tone, OverflowGate gate) {
+    if (frame_overflowed(gate)) return;          // (the surface keeps the frame before, overlay included)
     const uint32_t i = blockIdx.x * 64u + (threadIdx.x & 63u), j = blockIdx.y * 4u + (threadIdx.x >> 6);
     if (i >= sw || j >= sh) return;
     const float u = ((float)i + 0.5f) / (float)sw, v = ((float)j + 0.5f) / (float)sh;
@@ -2927,9 +2942,9 @@ void launch_detile_gathered(const uint8_t* gathered, uint64_t stride_bytes, uint
                        reinterpret_cast<const uint32_t*>(gathered), stride_bytes / 4, world, fc, reinterpret_cast<uint32_t*>(frame_rgba8));
 }
 void launch_present(const float* hdr, uint32_t w, uint32_t h, uint8_t* frame_rgba8, uint32_t sw, uint32_t sh,
-                    bool linear, uint32_t tone, hipStream_t stream) {
+                    bool linear, uint32_t tone, const OverflowGate& gate, hipStream_t stream) {
     hipLaunchKernelGGL(k_present, dim3(div_up(sw, 64), div_up(sh, 4)), dim3(256), 0, stream, hdr, w, h,
-                       reinterpret_cast<uint32_t*>(frame_rgba8), sw, sh, linear ? 1u : 0u, tone);
+                       reinterpret_cast<uint32_t*>(frame_rgba8), sw, sh, linear ? 1u : 0u, tone, gate);
 }
 void launch_overlay(const OverlayParams& p, uint32_t n_tiles, hipStream_t stream) {
     if (!n_tiles) return;

@@ -52,6 +52,11 @@ static constexpr uint32_t kQuadMeshId = 0xFFFFFFFEu;
 static __device__ __align__(256) unsigned char scratch[VisualServer::kScratchBytes];
 static constexpr int kMaxScratchDevices = 64;
 static void* g_scratch_ptr[kMaxScratchDevices] = {};
+// Who holds a device's array: the context of the last no-allocation frame and an event recorded behind that frame's
+// last kernel.  Another context that asks for the array while the event is pending is refused (RND_ERR_INVALID) instead
+// of racing; once it takes the array, the previous holder's frame is gone (its read-backs say RND_ERR_NO_FRAME).
+static hipEvent_t g_scratch_busy[kMaxScratchDevices] = {};
+static VisualServer* g_scratch_owner[kMaxScratchDevices] = {};
 static std::mutex g_scratch_mutex;
 
 // call with `device` current
@@ -62,6 +67,7 @@ static uint8_t* scratch_of_device(int device) {
         void* ptr = nullptr;
         HIP_CHECK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
         if (!ptr) throw Error(RND_ERR_DEVICE, "hipGetSymbolAddress returned a null scratch address");
+        HIP_CHECK(hipEventCreateWithFlags(&g_scratch_busy[device], hipEventDisableTiming));
         g_scratch_ptr[device] = ptr;
     }
     return static_cast<uint8_t*>(g_scratch_ptr[device]);
@@ -74,7 +80,6 @@ VisualServer::VisualServer(uint32_t width, uint32_t height, int device) : device
     HIP_CHECK(hipGetDeviceCount(&n_dev));
     if (device < 0 || device >= n_dev) throw Error(RND_ERR_INVALID, "no such HIP device");
     surface_w_ = width; surface_h_ = height;
-    if (const char* e = std::getenv("RND_GRAPH")) use_graphs_ = std::atoi(e) != 0;
     use_device();
     HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     for (auto& es : event_sets_)
@@ -100,7 +105,6 @@ VisualServer::VisualServer(uint32_t width, uint32_t height, int device) : device
         HIP_CHECK(hipEventCreateWithFlags(&shade_done_[k], hipEventDisableTiming));
     }
     if (const char* e = std::getenv("RND_OVERLAP")) overlap_ = std::atoi(e) != 0;
-    if (use_graphs_) overlap_ = false;      // a captured frame is one stream's sequence
     // SceneUniform defaults — visual_server.rs:63-68
     projection_ = perspective_lh(1.3f, 1.667f, 0.05f, 100.0f);
     view_ = Mat4::identity();
@@ -129,12 +133,14 @@ VisualServer::VisualServer(uint32_t width, uint32_t height, int device) : device
 
 VisualServer::~VisualServer() {
     (void)hipSetDevice(device_);
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (device_ >= 0 && device_ < kMaxScratchDevices && g_scratch_owner[device_] == this) g_scratch_owner[device_] = nullptr;
+    }
     try { comm_destroy(); } catch (...) {}
     if (geo_stream_) (void)hipStreamSynchronize(geo_stream_);
     if (stream_) (void)hipStreamSynchronize(stream_);
     shade_profile_dump();
-    for (CachedGraph& g : graphs_)
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (auto& kv : meshes_)
         for (auto& s : kv.second.submeshes) { s.vertex_buffer.release(); s.positions.release(); s.index_buffer.release(); s.chunks.release(); }
     for (int k = 0; k < 2; ++k) { d_tables_[k].release(); d_clip_[k].release(); d_vis_[k].release(); d_counters_[k].release(); }
@@ -726,6 +732,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     auto t_start = now(); auto t_prev = t_start;
     auto lap = [&](int k) { if (prof) { auto t = now(); acc[k] += std::chrono::duration<double, std::micro>(t - t_prev).count(); t_prev = t; } };
     use_device();
+    assembled_frame_ = false;
     poll_reports();                     // overflow reports of the frames in flight (no wait): streams grow before this frame is laid out
     if (scaled()) want_hdr = true;      // the present pass samples the HDR target
     const uint32_t p = parity_ ^ 1u;    // this frame's copy of the buffers that geometry writes and shading reads
@@ -739,6 +746,33 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     std::vector<GpuLight>& lights = gpu_lights_;
     std::vector<DrawItem>& shadow_items = shadow_items_;
     items.clear(); vert_bases.clear(); tri_bases.clear(); unit_bases.clear(); lights.clear(); shadow_items.clear();
+    // A no-allocation frame can be refused (what the scratch array cannot hold); a refused frame leaves the context as it
+    // was: what can be told beforehand is checked before anything changes, and what laying the frame out changes is put
+    // back when a later check refuses it.
+    struct Restore {
+        VisualServer& vs; bool armed;
+        FrameConst fc; Capacities cap; uint32_t clip_records; bool alpha, textured, early; uint32_t split;
+        ~Restore() {
+            if (!armed) return;
+            vs.fc_ = fc; vs.cap_ = cap; vs.clip_records_ = clip_records; vs.frame_alpha_test_ = alpha; vs.frame_textured_ = textured;
+            vs.early_z_frame_ = early; vs.split_units_ = split;
+        }
+    } restore{*this, noalloc, fc_, cap_, clip_records_, frame_alpha_test_, frame_textured_, early_z_frame_, split_units_};
+    if (noalloc) {
+        for (const RenderLight& l : lights_)
+            if (l.light.kind == RND_LIGHT_DIRECTIONAL) throw Error(RND_ERR_UNSUPPORTED, "rnd_render_noalloc: directional lights need 134 MB of shadow cascades each, beyond the scratch array");
+        if (scaled()) throw Error(RND_ERR_UNSUPPORTED, "rnd_render_noalloc: render_size_factor != 1 needs an HDR plane");
+        if (fullscreen_ != 0 || !uiboxes_.empty() || !glyphs_.empty()) throw Error(RND_ERR_UNSUPPORTED, "rnd_render_noalloc: the 2D overlay is not available here");
+        if (want_packed_ && d_packed_.count < (size_t)width_ * height_) throw Error(RND_ERR_UNSUPPORTED, "rnd_render_noalloc: the packed frame has not been allocated for this size");
+        const uint64_t need_out = world_ > 1 ? (uint64_t)n_owned_ * kTilePixels * 4 : (uint64_t)width_ * height_ * 4;
+        if (noalloc_bytes < need_out) throw Error(RND_ERR_INVALID, "rnd_render_noalloc: output buffer too small");
+        // the array may still be another context's
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        VisualServer* const holder = g_scratch_owner[device_];
+        if (holder && holder != this && hipEventQuery(g_scratch_busy[device_]) == hipErrorNotReady)
+            throw Error(RND_ERR_INVALID, "rnd_render_noalloc: another context's no-allocation frame is still in flight on this GPU (one scratch array per GPU)");
+        (void)hipGetLastError();
+    }
     {
         const char* const e = std::getenv("RND_EARLY_DEPTH");
         early_z_frame_ = e && *e ? std::atoi(e) != 0 : early_z_state_;
@@ -758,16 +792,8 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     const uint32_t n_views_max = n_sets ? kShadowCascades : 1u;        // views of the frame's widest pass (buffer sizes)
     static_assert(kShadowCascades <= kMaxViews && kShadowCascades * kShadowSize <= kMaxRenderSize, "the cascades must stack into one render target");
     const bool overlay = fullscreen_ != 0 || !uiboxes_.empty() || !glyphs_.empty();
-    if (noalloc) {
-        // what the scratch array cannot hold or what would need a new allocation
-        if (n_sets) throw Error(RND_ERR_UNSUPPORTED, "rnd_render_noalloc: directional lights need 134 MB of shadow cascades each, beyond the scratch array");
-        if (scaled()) throw Error(RND_ERR_UNSUPPORTED, "rnd_render_noalloc: render_size_factor != 1 needs an HDR plane");
-        if (overlay) throw Error(RND_ERR_UNSUPPORTED, "rnd_render_noalloc: the 2D overlay is not available here");
-        if (want_packed_ && d_packed_.count < (size_t)width_ * height_) throw Error(RND_ERR_UNSUPPORTED, "rnd_render_noalloc: the packed frame has not been allocated for this size");
-        const uint64_t need_out = world_ > 1 ? (uint64_t)n_owned_ * kTilePixels * 4 : (uint64_t)width_ * height_ * 4;
-        if (noalloc_bytes < need_out) throw Error(RND_ERR_INVALID, "rnd_render_noalloc: output buffer too small");
-        static_assert(kPinnedCounterSets >= 1, "a frame without shadow passes has one counter set, pinned at creation");
-    }
+    if (noalloc && n_sets) throw Error(RND_ERR_UNSUPPORTED, "rnd_render_noalloc: directional lights need shadow cascades beyond the scratch array");
+    static_assert(kPinnedCounterSets >= 1, "a frame without shadow passes has one counter set, pinned at creation");
     std::vector<ShadowSet> sets(n_sets);
     if (n_sets) {
         if (shadow_layers_[p].size() < n_sets) shadow_layers_[p].resize(n_sets);
@@ -919,6 +945,14 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         }
     }
     // nothing below rejects the frame
+    restore.armed = false;
+    if (noalloc) {
+        // the array changes hands: the previous holder's last frame (its visibility words, its counters) is gone
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        VisualServer* const holder = g_scratch_owner[device_];
+        if (holder && holder != this && holder->last_noalloc_) { holder->have_frame_ = false; holder->frame_pending_ = false; }
+        g_scratch_owner[device_] = this;
+    }
     parity_ = p;
     n_counter_sets_ = n_counter_sets;
     counter_set_ran_.assign(n_counter_sets_, 0);
@@ -991,9 +1025,16 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     fb.tiles_rgba8 = world_ > 1 ? (noalloc ? noalloc_out : ext_tiles_ ? ext_tiles_ : d_tiles_.ptr) : nullptr;
     fb.all_counters = bp.counters; fb.n_counter_sets = n_counter_sets;
     fb.ran_mask = ~0ull; fb.report = nullptr; fb.report_tag = 0;
-    if (!use_graphs_) {         // (a replayed graph would carry a stale tag: finish() alone watches such frames)
+    last_report_slot_ = kReportSlots;
+    {
         const uint32_t slot = report_next_;
         report_next_ = (report_next_ + 1) % kReportSlots;
+        if (report_expect_[slot]) {         // kReportSlots frames in flight: that frame's report must be seen before its slot is reused
+            HIP_CHECK(hipStreamSynchronize(stream_));
+            poll_reports();
+            report_expect_[slot] = 0;
+        }
+        last_report_slot_ = slot;
         report_tag_ = report_tag_ + 1u ? report_tag_ + 1u : 1u;
         report_expect_[slot] = report_tag_;
         fb.report = d_reports_ + slot; fb.report_tag = report_tag_;
@@ -1007,7 +1048,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
 
     // per-kernel timing events on a sample of the frames (every kTimingStride-th, and the first few):
     // eight event records per frame are a noticeable share of the host's enqueue time
-    const bool timed = force_timed_ > 0 || frame_counter_ < 4 || frame_counter_ % (use_graphs_ ? 4 * kTimingStride : kTimingStride) == 0;
+    const bool timed = force_timed_ > 0 || frame_counter_ < 4 || frame_counter_ % kTimingStride == 0;
     if (force_timed_) --force_timed_;
     ++frame_counter_;
     hipEvent_t* ev_ = nullptr;
@@ -1104,8 +1145,9 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         fb.ran_mask = ran;
     }
     launch_shade(fb, fc, stream_);
+    const OverflowGate gate{fb.all_counters, fb.n_counter_sets, 0u, fb.ran_mask};
     if (scaled())   // show_texture.wgsl over the surface (visual_server.rs:629-633: filtered sampler above factor 1)
-        launch_present(d_hdr_.ptr, width_, height_, d_present_.ptr, surface_w_, surface_h_, render_size_factor_ > 1.0f, tone_mapping_, stream_);
+        launch_present(d_hdr_.ptr, width_, height_, d_present_.ptr, surface_w_, surface_h_, render_size_factor_ > 1.0f, tone_mapping_, gate, stream_);
     if (overlay) {
         // Pipeline2d::render + the second draw of Backend::render, over the frame just presented
         OverlayParams op{};
@@ -1126,65 +1168,19 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         op.frame = world_ > 1 ? nullptr : reinterpret_cast<uint32_t*>(scaled() ? d_present_.ptr : d_frame_.ptr);
         op.tiles = world_ > 1 ? reinterpret_cast<uint32_t*>(fb.tiles_rgba8) : nullptr;
         op.overlay_out = d_overlay_.ptr;
+        op.gate = gate;
         if (world_ > 1) HIP_CHECK(hipMemsetAsync(d_overlay_.ptr, 0, (size_t)surface_w_ * surface_h_ * 4, stream_));
         launch_overlay(op, op.tiles_x * ((surface_h_ + kTile - 1) / kTile), stream_);
     }
     mark(6, stream_);
     if (overlap_) HIP_CHECK(hipEventRecord(shade_done_[p], stream_));
     };
-    // The kernel sequence only depends on buffer addresses, capacities and the scene's shape (the
-    // frame's constants and tables are read from device memory), so frames without timing events can
-    // replay it as a HIP graph: one launch call instead of a dozen.  Instantiated graphs are cached
-    // by a key of everything the launches take by value.  Opt-in (RND_GRAPH=1): measured on ROCm 7.2
-    // the replay costs the host as much as the launches (25.7 vs 30.1 us of 61 us per frame) and the
-    // frame rate does not move, so the plain launches stay the default.
-    bool launched = false;
-    if (use_graphs_ && !timed && !overlay && !overlap && !n_sets && !noalloc) {
-        std::vector<uint8_t> key;
-        auto add = [&](const void* p, size_t n) { const uint8_t* b = static_cast<const uint8_t*>(p); key.insert(key.end(), b, b + n); };
-        add(&fb, sizeof fb); add(&cap_, sizeof cap_);
-        for (const FrameConst& c : consts) {
-            const uint32_t dims[8] = {c.n_verts, c.n_units, c.n_tris, c.n_samples, c.width, c.height, c.tiles_x, c.tiles_y};
-            add(dims, sizeof dims);
-        }
-        for (uint32_t k = 0; k < n_sets; ++k) { const void* lp = shadow_layers_[p][k].ptr; add(&lp, sizeof lp); }
-        const void* ptrs[8] = {bp.counters, bp.vis, d_hdr_.ptr, d_present_.ptr, nullptr, tb, h, reinterpret_cast<const void*>(total)};
-        add(ptrs, sizeof ptrs);
-        const uint64_t misc[10] = {off_si, off_fc, n_sets, msaa_, surface_w_, surface_h_, width_, height_, tone_mapping_, render_size_factor_ > 1.0f ? 1u : 0u};
-        add(misc, sizeof misc);
-        CachedGraph* hit = nullptr;
-        for (CachedGraph& g : graphs_)
-            if (g.exec && g.key == key) { hit = &g; break; }
-        if (!hit) {
-            hipGraph_t graph = nullptr;
-            hipError_t e = hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal);
-            if (e == hipSuccess) {
-                emit();
-                e = hipStreamEndCapture(stream_, &graph);
-            }
-            hipGraphExec_t exec = nullptr;
-            if (e == hipSuccess && graph) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-            if (graph) (void)hipGraphDestroy(graph);
-            if (e == hipSuccess && exec) {
-                CachedGraph& slot = graphs_[graph_next_];
-                graph_next_ = (graph_next_ + 1) % kGraphSlots;
-                if (slot.exec) (void)hipGraphExecDestroy(slot.exec);
-                slot.exec = exec; slot.key = std::move(key);
-                hit = &slot;
-                if (std::getenv("RND_GRAPH_DEBUG")) std::fprintf(stderr, "rnd: captured a frame graph (%zu key bytes)\n", hit->key.size());
-            } else {
-                (void)hipGetLastError();
-                use_graphs_ = false;        // capture is not available here: plain launches from now on
-                if (std::getenv("RND_GRAPH_DEBUG")) std::fprintf(stderr, "rnd: graph capture failed (%s)\n", hipGetErrorString(e));
-            }
-        }
-        if (hit) { HIP_CHECK(hipGraphLaunch(hit->exec, stream_)); launched = true; }
-    }
-    if (!launched) emit();
+    emit();
     lap(3);
     if (timed_set) timed_set->pending = true;
+    if (noalloc) HIP_CHECK(hipEventRecord(g_scratch_busy[device_], stream_));
     // the pinned block is free again once this frame's first kernel has read it; recorded after the
-    // whole geometry sequence so that it also holds for a graph replay (three blocks rotate)
+    // whole geometry sequence (three blocks rotate)
     HIP_CHECK(hipEventRecord(st.done, gs));
     st.in_flight = true;
     serialize_next_ = timed;
@@ -1278,6 +1274,8 @@ void VisualServer::finish() {
         // an internal stream was too small: grow it to what the frame asked for and run it again
         grow_streams(c.overflow, c.n_records, c.n_clip, c.n_entries);
         grew = 1;
+        // (this frame is re-run here and delivered: its own report must not come back as the notice of a dropped frame)
+        if (last_report_slot_ < kReportSlots) report_expect_[last_report_slot_] = 0;
         if (last_noalloc_) {
             // growing means allocating: the frame in the caller's buffer is incomplete and stays so; the next
             // frame (either entry point) is laid out with the capacities learnt here
@@ -1351,6 +1349,11 @@ void VisualServer::need_frame() const {
 void VisualServer::read_color_rgba8(uint8_t* dst) {
     if (!dst) throw Error(RND_ERR_INVALID, "null destination");
     finish(); need_frame(); use_device();
+    if (assembled_frame_) {     // rank 0 after rnd_gather_tiles / rnd_composite_packed: the whole frame, as assembled
+        HIP_CHECK(hipMemcpyAsync(dst, d_frame_.ptr, (size_t)width_ * height_ * 4, hipMemcpyDeviceToHost, stream_));
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        return;
+    }
     if (world_ > 1) {   // a partitioned context holds only its tiles: assemble them over a cleared frame
         HIP_CHECK(hipMemsetAsync(d_frame_.ptr, 0, (size_t)width_ * height_ * 4, stream_));
         detile(rank_, world_, last_tiles_out_);

@@ -193,12 +193,6 @@ private:
     EventSet event_sets_[kEventSets];
     uint32_t event_next_ = 0;
     static constexpr uint64_t kTimingStride = 256;    // a timed frame runs un-overlapped (two serialization points): keep them rare
-    // instantiated HIP graphs of the frame's kernel sequence, keyed by the launches' by-value arguments
-    static constexpr int kGraphSlots = 8;      // the key cycles through 3 staging blocks x 2 frame parities
-    struct CachedGraph { std::vector<uint8_t> key; hipGraphExec_t exec = nullptr; };
-    CachedGraph graphs_[kGraphSlots];
-    int graph_next_ = 0;
-    bool use_graphs_ = false;     // RND_GRAPH=1 turns them on (no gain measured on ROCm 7.2: hipGraphLaunch costs the host what the launches do)
     uint64_t frame_counter_ = 0;
     int last_set_ = -1;
     static constexpr int kTimingFields = sizeof(rnd_timings) / sizeof(float);
@@ -306,11 +300,12 @@ private:
     bool pending_want_hdr_ = false;           // the frame finish() may have to run again wanted the HDR plane
     // Overflow reports of the frames in flight (FrameReport in mapped pinned memory, written by each frame's shading
     // kernel): looked at without synchronizing when the next frame is enqueued.
-    static constexpr uint32_t kReportSlots = 8;
+    static constexpr uint32_t kReportSlots = 64;          // frames in flight whose reports are awaited (a slot still awaited when its turn comes again is waited for)
     FrameReport* h_reports_ = nullptr;        // pinned, mapped
     FrameReport* d_reports_ = nullptr;        // the same block as the device addresses it
     uint32_t report_expect_[kReportSlots] = {};   // tag each slot is waiting for (0: none)
     uint32_t report_next_ = 0, report_tag_ = 0;
+    uint32_t last_report_slot_ = kReportSlots;        // the slot of the last enqueued frame (kReportSlots: none)
     bool truncated_notice_ = false;           // a frame in flight was found truncated: the next render() says so once
     bool test_small_streams_ = false;         // RND_TEST_SMALL_STREAMS=1: start with tiny streams (overflow tests)
     void poll_reports();
@@ -325,6 +320,7 @@ private:
     // and above the next frames run k_setup's early-depth variant with the items near to far, below 4 the plain one again.
     // RND_EARLY_DEPTH = 0 / 1 forces one (read per frame).
     bool early_z_state_ = false, early_z_frame_ = false;
+    bool assembled_frame_ = false;              // d_frame_ holds a frame assembled from every rank (gather_tiles / composite_packed), until the next render
     uint32_t split_units_ = 0;                  // units of the early-depth variant's first pass (build_frame)
     DeviceBuffer<float> d_hiz_;                 // farthest depth per 8x8 block between its two passes
     void note_depth_complexity(uint64_t n_fragments);

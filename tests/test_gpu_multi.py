@@ -140,11 +140,11 @@ def test_overlapped_frames_keep_their_own_output():
     assert len(distinct) >= 6          # the frames really differ from each other
 
 
-@pytest.mark.parametrize("env", [{"RND_OVERLAP": "0"}, {"RND_GRAPH": "1"}])
-def test_single_stream_and_graph_modes(env):
-    """The two launch modes chosen by environment variables at context creation (everything on the
-    caller's stream; the frame's kernel sequence replayed as a HIP graph) render the same frames as the
-    default mode: a child process renders a run of frames in that mode and checks them against the oracle."""
+@pytest.mark.parametrize("env", [{"RND_OVERLAP": "0"}, {"RND_OVERLAP": "0", "RND_EARLY_DEPTH": "1"}])
+def test_single_stream_mode(env):
+    """The launch mode chosen by an environment variable at context creation (everything on the caller's stream, no
+    overlap of a frame's geometry with the frame before) renders the same frames as the default mode: a child process
+    renders a run of frames in that mode and checks them against the oracle."""
     import os
     import subprocess
     import sys

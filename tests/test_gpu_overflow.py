@@ -70,8 +70,20 @@ print("overflow ok")
 '''
 
 
-def test_truncated_frames_are_not_presented():
+@pytest.mark.parametrize("overlay", [False, True], ids=["plain", "translucent-overlay"])
+def test_truncated_frames_are_not_presented(overlay):
+    """With a translucent UI box over the frame: the 2D pass blends in place, so running it over an image
+    that a truncated frame left alone would composite the box a second time — the overlay and present kernels take the
+    same overflow gate as the shading kernel."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-c", CODE], cwd=root, env={**os.environ, "RND_TEST_SMALL_STREAMS": "1", "PYTHONPATH": root},
+    code = CODE
+    if overlay:
+        code = code.replace("cpu = oracle_server(w, h); s.populate(cpu); cpu.render()",
+                            "boxes = [((20.0, 30.0), (200.0, 90.0), (0.9, 0.2, 0.1, 0.5)), ((100.0, 60.0), (150.0, 120.0), (0.1, 0.8, 0.3, 0.35))]\n"
+                            "cpu = oracle_server(w, h); s.populate(cpu); cpu.set_uiboxes(boxes); cpu.render()")
+        code = code.replace("s.populate(vs)\nshots, notices = [], 0", "s.populate(vs)\nvs.set_uiboxes(boxes)\nshots, notices = [], 0")
+        code = code.replace("s.populate(vs2)\nvs2.render()", "s.populate(vs2)\nvs2.set_uiboxes(boxes)\nvs2.render()")
+        assert code.count("set_uiboxes") == 3
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env={**os.environ, "RND_TEST_SMALL_STREAMS": "1", "PYTHONPATH": root},
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "overflow ok" in out.stdout, (out.stdout[-800:], out.stderr[-2000:])

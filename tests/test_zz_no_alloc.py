@@ -89,3 +89,44 @@ def test_noalloc_rejects_what_it_cannot_hold():
     # and the context is still good
     vs.render()
     assert vs.read_coverage().mean() > 0.5
+
+
+def test_noalloc_refusal_changes_nothing_and_the_array_has_one_holder():
+    """a refused frame leaves the context as it was (the read-backs still describe the frame before), and
+    the one scratch array of a GPU has one holder: when another context takes it, the previous holder's frame is gone
+    (RND_ERR_NO_FRAME from its read-backs) instead of showing the other context's data."""
+    import torch
+    out = torch.zeros((360, 640, 4), dtype=torch.uint8, device="cuda")
+    a = VisualServer(640, 360, device=0)
+    s = soup_scene(8, 640, 360, n_meshes=3, n_tri=50, lights=2)
+    s.lights = [l for l in s.lights if l[2].kind_id() == 1]
+    s.populate(a)
+    a.render_noalloc(out.data_ptr(), out.numel())
+    a.finish()
+    ids0, depth0 = planes(a)
+    stats0 = a.frame_stats()
+    # refused after the frame was laid out (2.2 M triangles do not fit the array): nothing of it may stick
+    huge = c2_grid_1m(width=640, height=360, scale=1.5)
+    handles = [a.asset_server.add(m) for m in huge.meshes]
+    for nid, t, m in huge.instances:
+        a.set_mesh_instance(1000 + nid, t, handles[m])
+    with pytest.raises(RndError):
+        a.render_noalloc(out.data_ptr(), out.numel())
+    ids1, depth1 = planes(a)
+    assert (ids1 == ids0).all() and (depth1 == depth0).all()
+    assert a.frame_stats() == stats0
+    # another context takes the array: a's frame is gone, b's is right
+    b = VisualServer(640, 360, device=0)
+    s.populate(b)
+    out_b = torch.zeros_like(out)
+    b.render_noalloc(out_b.data_ptr(), out_b.numel())
+    b.finish()
+    assert (planes(b)[0] == ids0).all()
+    with pytest.raises(RndError) as e:
+        a.read_depth()
+    assert e.value.code == -6
+    # and a renders again through the allocating entry point as if nothing had happened
+    a.reset_scene()
+    s.populate(a)
+    a.render()
+    assert (planes(a)[0] == ids0).all()
