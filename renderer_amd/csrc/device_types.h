@@ -183,7 +183,7 @@ struct FrameCounters;
 struct OverflowGate {
     const FrameCounters* all_counters;
     uint32_t n_counter_sets;
-    uint32_t pad;
+    uint32_t no_chain;            // the frame was launched without k_clip .. k_raster: it is also withheld when a pass turns out to need them
     uint64_t ran_mask;            // bit s: counter set s was written this frame (sets beyond 63: assumed)
 };
 
@@ -213,13 +213,17 @@ struct FrameCounters {
     uint32_t all_verts;        // a surviving unit uses a wide vertex range: transform every vertex block
     uint32_t n_wide;           // records on the wide list (not binned: every tile's raster workgroup checks them)
     uint32_t n_extra;          // (tile, slice) work items of heavy tiles beyond their first raster workgroup
-    uint32_t n_fragments;      // covered samples k_setup's direct path resolved (saturating; summed by k_scan_tiles)
-    uint32_t pad[2];
+    uint32_t n_fragments;      // pixel centres in the bboxes of the triangles k_setup rasterizes itself (saturating; summed by k_scan_tiles, or by k_shade in a frame without the record chain)
+    uint32_t chain_needed;     // k_setup wrote a record or queued a triangle for the clipper: the pass needs k_clip .. k_raster
+    uint32_t pad[1];
 };
 
 // What the frame's shading kernel reports to the host through mapped pinned memory, so that the host learns of an
 // overflow without synchronizing: OR / maximum over the counter sets of the frame's passes.  `frame_tag` is
 // written last (after a system-scope fence); a report belongs to the frame whose tag it carries.
+// overflow: bits 0..2 as FrameCounters::overflow; kReportNoChainFailed: the frame ran without the record chain, needed it and
+// was withheld; kReportChainNeeded: some pass wrote records or queued triangles for the clipper.
+constexpr uint32_t kReportNoChainFailed = 8u, kReportChainNeeded = 16u;
 struct FrameReport {
     uint32_t overflow, n_records, n_clip, n_entries;
     uint32_t n_fragments;      // the main pass's FrameCounters::n_fragments: depth complexity = n_fragments / (pixels * samples)

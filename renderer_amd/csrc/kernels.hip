@@ -42,15 +42,17 @@ __device__ __forceinline__ bool guard(bool ok, FrameCounters* counters, uint32_t
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
-// Whether any pass of the frame overflowed an internal stream (records, clip queue, bin entries): wave-uniform scalar loads.
+// Whether the frame is withheld: a pass overflowed an internal stream (records, clip queue, bin entries), or the frame was
+// launched without the record chain (k_clip .. k_raster) and a pass turned out to need it.  Wave-uniform scalar loads.
 __device__ __forceinline__ bool frame_overflowed(const OverflowGate& g) {
     typedef const __attribute__((address_space(4))) FrameCounters* cptr_counters;
-    uint32_t ovf = 0;
+    uint32_t ovf = 0, need = 0;
     for (uint32_t s = 0; s < g.n_counter_sets; ++s) {
         if (s < 64u && !((g.ran_mask >> s) & 1ull)) continue;
         ovf |= ((cptr_counters)g.all_counters + s)->overflow;
+        need |= ((cptr_counters)g.all_counters + s)->chain_needed;
     }
-    return (ovf & 7u) != 0u;
+    return (ovf & 7u) != 0u || (g.no_chain != 0u && need != 0u);
 }
 
 // The frame's constants live in device memory (uploaded with the per-frame tables), not in the kernel
@@ -941,6 +943,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
         // queue the triangles that need the clipper (wave-compacted, rare)
         unsigned long long cm = __ballot(need_clip);
         if (cm) {
+            if (lane == 0) fb.counters->chain_needed = 1u;       // (frames launched without k_clip .. k_raster are withheld and re-run: k_shade's gate)
             int leader = __ffsll((long long)cm) - 1;
             uint32_t base = 0;
             if (lane == (uint32_t)leader) base = atomicAdd(&fb.counters->n_clip, (uint32_t)__popcll(cm));
@@ -1038,7 +1041,7 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
         const unsigned long long em = __ballot(emit);
         if (em == 0ull) continue;
         uint32_t wave_base = 0;
-        if (lane == 0) wave_base = atomicAdd(&s_used, (uint32_t)__popcll(em));
+        if (lane == 0) { fb.counters->chain_needed = 1u; wave_base = atomicAdd(&s_used, (uint32_t)__popcll(em)); }
         wave_base = __builtin_amdgcn_readfirstlane(wave_base);
         const uint32_t slot = chunk_base + wave_base + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
         const uint32_t pos = count_wave(emit, tr, slot, fc, fb.tile_count, fb.tile_count + n_tiles, fb.counters, fb.wide_list, cap.wide_list);
@@ -2234,20 +2237,42 @@ __global__ __launch_bounds__(256, kShadows ? (kSamples > 1 ? 1 : 5) : (kSamples 
     // from the report (no synchronization) and has grown the streams by the next frame; rnd_finish re-runs it.
     {
         typedef const __attribute__((address_space(4))) FrameCounters* cptr_counters;      // scalar loads
-        uint32_t ovf = 0, n_rec = 0, n_clip = 0, n_ent = 0;
+        uint32_t ovf = 0, n_rec = 0, n_clip = 0, n_ent = 0, need = 0;
         for (uint32_t s = 0; s < fb.n_counter_sets; ++s) {
             if (s < 64u && !((fb.ran_mask >> s) & 1ull)) continue;
             cptr_counters c = (cptr_counters)fb.all_counters + s;
             ovf |= c->overflow; n_rec = max(n_rec, c->n_records); n_clip = max(n_clip, c->n_clip); n_ent = max(n_ent, c->n_entries);
+            need |= c->chain_needed;
         }
-        if (blockIdx.x == 0 && tid == 0 && fb.report) {
-            volatile FrameReport* r = fb.report;
-            r->overflow = ovf; r->n_records = n_rec; r->n_clip = n_clip; r->n_entries = n_ent;
-            r->n_fragments = ((cptr_counters)fb.main_counters)->n_fragments;      // (the main pass's: the host picks its k_setup variant by it)
-            __threadfence_system();
-            r->frame_tag = fb.report_tag;
+        // A frame launched without the record chain (the host does that after a run of frames that needed none of it) whose
+        // setup did write records or queue triangles for the clipper is withheld like an overflowed one, and re-run in full.
+        const bool no_chain_failed = fb.no_chain != 0u && need != 0u;
+        if (blockIdx.x == 0 && fb.report) {
+            uint32_t frags = ((cptr_counters)fb.main_counters)->n_fragments;       // (the main pass's: the host picks its k_setup variant by it)
+            if (fb.no_chain) {
+                // k_scan_tiles did not run: the main pass's statistics are summed here, by this one workgroup
+                __shared__ unsigned long long s_sum[2];
+                if (tid == 0) { s_sum[0] = 0ull; s_sum[1] = 0ull; }
+                __syncthreads();
+                const uint32_t n_units = fc.n_units, n_active = min(((cptr_counters)fb.main_counters)->n_active, n_units);
+                unsigned long long v = 0, fr = 0;
+                for (uint32_t c = tid; c < n_active; c += 256u) { v += fb.chunk_count[n_units + c]; fr += fb.chunk_count[2u * n_units + c]; }
+                for (int o = 32; o > 0; o >>= 1) { v += __shfl_xor(v, o); fr += __shfl_xor(fr, o); }
+                if (lane == 0) { atomicAdd(&s_sum[0], v); atomicAdd(&s_sum[1], fr); }
+                __syncthreads();
+                frags = (uint32_t)min(s_sum[1], 0xFFFFFFFFull);
+                if (tid == 0) { fb.counters->n_valid = (uint32_t)min(s_sum[0], 0xFFFFFFFFull); fb.counters->n_fragments = frags; }
+            }
+            if (tid == 0) {
+                volatile FrameReport* r = fb.report;
+                r->overflow = (ovf & 7u) | (no_chain_failed ? kReportNoChainFailed : 0u) | (need ? kReportChainNeeded : 0u);
+                r->n_records = n_rec; r->n_clip = n_clip; r->n_entries = n_ent;
+                r->n_fragments = frags;
+                __threadfence_system();
+                r->frame_tag = fb.report_tag;
+            }
         }
-        if (ovf & 7u) return;          // (uniform over the grid; before any barrier)
+        if ((ovf & 7u) || no_chain_failed) return;          // (uniform over the grid; before any barrier the whole grid takes)
     }
     if constexpr (kShadows) {
         s_lut[tid] = lut0; s_lut[256u + tid] = lut1;

@@ -105,6 +105,7 @@ VisualServer::VisualServer(uint32_t width, uint32_t height, int device) : device
         HIP_CHECK(hipEventCreateWithFlags(&shade_done_[k], hipEventDisableTiming));
     }
     if (const char* e = std::getenv("RND_OVERLAP")) overlap_ = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RND_NO_CHAIN")) allow_no_chain_ = std::atoi(e) != 0;
     // SceneUniform defaults — visual_server.rs:63-68
     projection_ = perspective_lh(1.3f, 1.667f, 0.05f, 100.0f);
     view_ = Mat4::identity();
@@ -145,7 +146,7 @@ VisualServer::~VisualServer() {
         for (auto& s : kv.second.submeshes) { s.vertex_buffer.release(); s.positions.release(); s.index_buffer.release(); s.chunks.release(); }
     for (int k = 0; k < 2; ++k) { d_tables_[k].release(); d_clip_[k].release(); d_vis_[k].release(); d_counters_[k].release(); }
     d_snap_.release(); d_hiz_.release(); d_wide_list_.release(); d_tile_slices_.release(); d_raster_extra_.release();
-    d_records_.release(); d_tilewords_.release(); d_clip_queue_.release(); d_chunk_count_.release(); d_vblock_needed_.release(); d_active_units_.release(); d_tile_count_.release();
+    d_records_.release(); d_tilewords_.release(); d_clip_queue_.release(); d_chunk_count_[0].release(); d_chunk_count_[1].release(); d_vblock_needed_.release(); d_active_units_.release(); d_tile_count_.release();
     d_tile_offset_.release(); d_tile_cursor_.release(); d_entries_.release();
     for (auto& kv : textures_) kv.second.texels.release();
     d_textures_.release();
@@ -182,6 +183,7 @@ void VisualServer::apply_size(uint32_t sw, uint32_t sh, float f) {
     if (w == 0 || h == 0 || w > kMaxRenderSize || h > kMaxRenderSize) throw Error(RND_ERR_INVALID, "render size * factor must be in 1..8192");
     if (f != 1.0f && world_ > 1) throw Error(RND_ERR_UNSUPPORTED, "render_size_factor != 1 on a tile partition is not built");
     finish();
+    chain_free_streak_ = 0;          // (a changed scene or target: the record chain again until frames show they do not need it)
     surface_w_ = sw; surface_h_ = sh; width_ = w; height_ = h; render_size_factor_ = f;
     ext_tiles_ = nullptr; ext_tiles_bytes_ = 0; ext_packed_ = nullptr;
     have_frame_ = false;
@@ -194,6 +196,7 @@ void VisualServer::set_msaa(uint32_t n) {
     if (n != 1 && n != 4) throw Error(RND_ERR_INVALID, "sample count must be 1 or 4");
     if (n == msaa_) return;
     finish();
+    chain_free_streak_ = 0;          // (a changed scene or target: the record chain again until frames show they do not need it)
     msaa_ = n;
     have_frame_ = false;
     rebuild_tiles();    // recreate_render_targets (visual_server.rs:178-181): one visibility plane per sample
@@ -240,6 +243,7 @@ void VisualServer::set_tile_partition(uint32_t rank, uint32_t world) {
     if (world == 0 || rank >= world) throw Error(RND_ERR_INVALID, "rank must be < world");
     if (world > 1 && scaled()) throw Error(RND_ERR_UNSUPPORTED, "render_size_factor != 1 on a tile partition is not built");
     finish();
+    chain_free_streak_ = 0;          // (a changed scene or target: the record chain again until frames show they do not need it)
     rank_ = rank; world_ = world;
     ext_tiles_ = nullptr; ext_tiles_bytes_ = 0;
     have_frame_ = false;
@@ -264,6 +268,7 @@ void VisualServer::register_mesh(uint32_t mesh_id, uint32_t n_submeshes, const r
     }
     use_device();
     finish();
+    chain_free_streak_ = 0;          // (a changed scene or target: the record chain again until frames show they do not need it)
     auto old = meshes_.find(mesh_id);
     if (old != meshes_.end()) {
         for (auto& s : old->second.submeshes) { s.vertex_buffer.release(); s.positions.release(); s.index_buffer.release(); s.chunks.release(); }
@@ -413,6 +418,7 @@ void VisualServer::set_sprite(UniqueNodeId id, const Mat4& transform, uint32_t t
 void VisualServer::reset_scene() {
     use_device();
     finish();
+    chain_free_streak_ = 0;          // (a changed scene or target: the record chain again until frames show they do not need it)
     for (auto it = meshes_.begin(); it != meshes_.end();) {
         if (it->first == kQuadMeshId) { ++it; continue; }
         for (auto& s : it->second.submeshes) { s.vertex_buffer.release(); s.positions.release(); s.index_buffer.release(); s.chunks.release(); }
@@ -874,7 +880,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         d_snap_.ensure(n_view_verts);
         d_records_.ensure(cap_.records); d_tilewords_.ensure(2 * (size_t)cap_.records);
         d_clip_queue_.ensure(2 * (size_t)cap_.clip_queue);
-        d_chunk_count_.ensure(n_count_words);
+        d_chunk_count_[p].ensure(n_count_words);       // (by frame parity: a frame without the record chain has its statistics summed by its shading kernel)
         d_active_units_.ensure(n_unit_words);
         d_vblock_needed_.ensure(n_vblocks);
         d_entries_.ensure(cap_.entries);
@@ -885,7 +891,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         if (want_packed_) d_packed_.ensure((size_t)width_ * height_);
         if (want_hdr) d_hdr_.ensure((size_t)width_ * height_ * 3);
         bp.clip = store_clip && store_clip_fits ? d_clip_[p].ptr : nullptr; bp.snap = d_snap_.ptr; bp.records = d_records_.ptr; bp.tilewords = d_tilewords_.ptr; bp.clip_queue = d_clip_queue_.ptr;
-        bp.chunk_count = d_chunk_count_.ptr; bp.active_units = d_active_units_.ptr; bp.vblock_needed = d_vblock_needed_.ptr; bp.entries = d_entries_.ptr;
+        bp.chunk_count = d_chunk_count_[p].ptr; bp.active_units = d_active_units_.ptr; bp.vblock_needed = d_vblock_needed_.ptr; bp.entries = d_entries_.ptr;
         bp.wide_list = d_wide_list_.ptr; bp.tile_slices = d_tile_slices_.ptr; bp.raster_extra = d_raster_extra_.ptr;
         bp.tile_count = d_tile_count_.ptr; bp.tile_offset = d_tile_offset_.ptr; bp.tile_cursor = d_tile_cursor_.ptr;
         bp.counters = d_counters_[p].ptr; bp.vis = d_vis_[p].ptr;
@@ -1012,6 +1018,11 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     fb.tile_count = bp.tile_count; fb.tile_offset = bp.tile_offset; fb.tile_cursor = bp.tile_cursor;
     fb.wide_list = bp.wide_list; fb.tile_slices = bp.tile_slices; fb.raster_extra = bp.raster_extra;
     fb.entries = bp.entries; fb.counters = bp.counters; fb.main_counters = bp.counters;
+    // without the record chain: after a run of frames that needed none of it (never the no-allocation frame, whose
+    // statistics nobody could sum: its chunk counts live in the shared array)
+    frame_no_chain_ = allow_no_chain_ && !noalloc && full_chain_frames_ == 0 && chain_free_streak_ >= kNoChainStreak;
+    if (full_chain_frames_) --full_chain_frames_;
+    fb.no_chain = frame_no_chain_ ? 1u : 0u;
     fb.early_z = early_z_frame_ ? 1u : 0u;
     fb.split_units = split_units_;
     fb.setup_pass = early_z_frame_ && split_units_ != 0u && split_units_ < fc.n_units ? 1u : 0u;
@@ -1113,6 +1124,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         launch_cull(sfb, sfc, gs);
         launch_transform(sfb, sfc, gs);
         launch_setup(sfb, sfc, cap_, gs);
+        if (frame_no_chain_) continue;
         launch_clip(sfb, sfc, cap_, gs);
         launch_scan(sfb, sfc, cap_, gs);
         launch_bin(sfb, sfc, cap_, gs);
@@ -1128,13 +1140,13 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     mark(1, gs);
     launch_setup(fb, fc, cap_, gs);
     mark(11, gs);
-    launch_clip(fb, fc, cap_, gs);
+    if (!frame_no_chain_) launch_clip(fb, fc, cap_, gs);
     mark(2, gs);
-    launch_scan(fb, fc, cap_, gs);
+    if (!frame_no_chain_) launch_scan(fb, fc, cap_, gs);
     mark(3, gs);
-    launch_bin(fb, fc, cap_, gs);
+    if (!frame_no_chain_) launch_bin(fb, fc, cap_, gs);
     mark(4, gs);
-    launch_raster(fb, fc, cap_, gs);
+    if (!frame_no_chain_) launch_raster(fb, fc, cap_, gs);
     mark(5, gs);
     if (overlap_) HIP_CHECK(hipEventRecord(geo_done_[p], gs));
     if (overlap) HIP_CHECK(hipStreamWaitEvent(stream_, geo_done_[p], 0));
@@ -1145,7 +1157,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         fb.ran_mask = ran;
     }
     launch_shade(fb, fc, stream_);
-    const OverflowGate gate{fb.all_counters, fb.n_counter_sets, 0u, fb.ran_mask};
+    const OverflowGate gate{fb.all_counters, fb.n_counter_sets, fb.no_chain, fb.ran_mask};
     if (scaled())   // show_texture.wgsl over the surface (visual_server.rs:629-633: filtered sampler above factor 1)
         launch_present(d_hdr_.ptr, width_, height_, d_present_.ptr, surface_w_, surface_h_, render_size_factor_ > 1.0f, tone_mapping_, gate, stream_);
     if (overlay) {
@@ -1210,6 +1222,12 @@ void VisualServer::render() {
     }
 }
 
+void VisualServer::note_chain(bool needed, bool failed) {
+    if (failed) { full_chain_frames_ = kFullChainFrames; chain_free_streak_ = 0; }
+    else if (needed) chain_free_streak_ = 0;
+    else if (chain_free_streak_ < 0xFFFFFFFFu) ++chain_free_streak_;
+}
+
 void VisualServer::note_depth_complexity(uint64_t n_fragments) {
     // (n_fragments: pixel centres in the bboxes of the small triangles, about twice what they cover: C3 1.4 per pixel,
     // C4 — ten layers — 30)
@@ -1233,7 +1251,9 @@ void VisualServer::poll_reports() {
         if (r->frame_tag != report_expect_[s]) continue;       // not there yet
         report_expect_[s] = 0;
         note_depth_complexity(r->n_fragments);
-        const uint32_t ovf = r->overflow & 7u;
+        const uint32_t flags = r->overflow, ovf = flags & 7u;
+        note_chain((flags & kReportChainNeeded) != 0u || ovf != 0u, (flags & kReportNoChainFailed) != 0u);
+        if (flags & kReportNoChainFailed) truncated_notice_ = true;        // (withheld: the frame is lost unless rnd_finish re-runs it)
         if (!ovf) continue;
         grow_streams(ovf, r->n_records, r->n_clip, r->n_entries);
         truncated_notice_ = true;
@@ -1265,15 +1285,26 @@ void VisualServer::finish() {
             c.n_records = std::max(c.n_records, o.n_records); c.n_clip = std::max(c.n_clip, o.n_clip);
             c.n_entries = std::max(c.n_entries, o.n_entries);
         }
+        bool chain_needed = c.chain_needed != 0u;
+        for (uint32_t k = 1; k < n_counter_sets_; ++k) if (counter_set_ran_[k]) chain_needed = chain_needed || h_counters_[k].chain_needed != 0u;
         if (c.overflow & ~7u) {
             char msg[96];
             std::snprintf(msg, sizeof msg, "internal consistency check failed in a kernel (flags 0x%x)", c.overflow);
             throw Error(RND_ERR_DEVICE, msg);
         }
+        if (!c.overflow && frame_no_chain_ && chain_needed) {
+            // launched without the record chain, needed it, was withheld: run it again in full (and its report is handled here)
+            if (last_report_slot_ < kReportSlots) report_expect_[last_report_slot_] = 0;
+            note_chain(true, true);
+            if (attempt == 7) throw Error(RND_ERR_DEVICE, "frame could not be completed");
+            enqueue_frame(pending_want_hdr_);
+            continue;
+        }
         if (!c.overflow) break;
         // an internal stream was too small: grow it to what the frame asked for and run it again
         grow_streams(c.overflow, c.n_records, c.n_clip, c.n_entries);
         grew = 1;
+        note_chain(true, frame_no_chain_ && chain_needed);
         // (this frame is re-run here and delivered: its own report must not come back as the notice of a dropped frame)
         if (last_report_slot_ < kReportSlots) report_expect_[last_report_slot_] = 0;
         if (last_noalloc_) {

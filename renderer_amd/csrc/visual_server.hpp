@@ -254,7 +254,7 @@ private:
     DeviceBuffer<float4> d_clip_[2];
     DeviceBuffer<SnapVert> d_snap_;
     DeviceBuffer<SetupRecord> d_records_;
-    DeviceBuffer<uint32_t> d_tilewords_, d_clip_queue_, d_chunk_count_, d_vblock_needed_, d_active_units_, d_tile_count_, d_tile_offset_, d_tile_cursor_, d_entries_;
+    DeviceBuffer<uint32_t> d_tilewords_, d_clip_queue_, d_chunk_count_[2], d_vblock_needed_, d_active_units_, d_tile_count_, d_tile_offset_, d_tile_cursor_, d_entries_;
     DeviceBuffer<FrameCounters> d_counters_[2];     // [0] main pass, then one per shadow pass
     uint32_t n_counter_sets_ = 1, h_counter_sets_ = 0;
     // shadow cascades of the directional lights
@@ -320,6 +320,16 @@ private:
     // and above the next frames run k_setup's early-depth variant with the items near to far, below 4 the plain one again.
     // RND_EARLY_DEPTH = 0 / 1 forces one (read per frame).
     bool early_z_state_ = false, early_z_frame_ = false;
+    // Frames without the record chain.  A pass whose triangles all take k_setup's direct path needs none of k_clip,
+    // k_scan_tiles, k_bin_fill, k_raster — four launches of a latency-bound chain that is most of a small frame.  After
+    // kNoChainStreak reported frames in a row that needed none of them the next frames are launched without; a frame
+    // that then does need them is withheld by k_shade (as an overflowed one: the image keeps the frame before, the
+    // report says so, rnd_finish re-runs it) and the full chain comes back for kFullChainFrames frames.
+    // RND_NO_CHAIN=0 never leaves the chain out.
+    static constexpr uint32_t kNoChainStreak = 4, kFullChainFrames = 64;
+    uint32_t chain_free_streak_ = 0, full_chain_frames_ = 0;
+    bool frame_no_chain_ = false, allow_no_chain_ = true;
+    void note_chain(bool needed, bool failed);
     bool assembled_frame_ = false;              // d_frame_ holds a frame assembled from every rank (gather_tiles / composite_packed), until the next render
     uint32_t split_units_ = 0;                  // units of the early-depth variant's first pass (build_frame)
     DeviceBuffer<float> d_hiz_;                 // farthest depth per 8x8 block between its two passes
