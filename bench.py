@@ -16,6 +16,7 @@ Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -162,9 +163,13 @@ def main():
         desc += f" (first {args.lights} lights only)"
 
     n_tris = scene.n_triangles
+    scene_all = scene
+    pending_last = [None]
     sort_last = world > 1 and (args.partition == "sort-last" or (args.partition == "auto" and args.workload == "c5"))
     if sort_last:
-        scene.instances = scene.instances[rank::world]          # this rank's shard of the instances (meshes are shared)
+        import copy
+        scene = copy.copy(scene_all)
+        scene.instances = scene_all.instances[rank::world]      # this rank's shard of the instances (meshes are shared)
     vs = VisualServer(scene.width, scene.height, device=local_rank)
     stream = torch.cuda.Stream(device=local_rank)
     vs.set_stream(stream.cuda_stream)
@@ -222,6 +227,7 @@ def main():
                 comm.wait_event(ev["reduced"][b])
                 comm.wait_event(ev["unpacked"][b])
                 done = strips.collect(b)
+                pending_last[0] = done
                 ev["collected"][b].record(comm)
             if rank == 0:
                 with torch.cuda.stream(stream):
@@ -305,6 +311,15 @@ def main():
     fence()
     mean, worst, n_frames = vs.timing_stats()
     stats = vs.frame_stats()
+    frame_check = None
+    if world > 1:
+        frame_check = check_assembled_frame(vs, scene_all, sort_last, strips, pending_last, rank, local_rank)
+        ok = torch.tensor([0 if frame_check is None or frame_check.startswith("ok") else 1], device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(ok)
+        if int(ok.item()):
+            if rank == 0:
+                print("bench: the assembled frame differs from the single-GPU frame: " + str(frame_check), file=sys.stderr)
+            raise SystemExit(3)
     ms_per_step = elapsed / args.steps * 1e3
     fps = args.steps / elapsed
     result = None
@@ -322,15 +337,23 @@ def main():
         for k in ("cull", "clip", "scan"):
             kernels[k] = {"ms": round(mean[k + "_ms"], 5), "ms_max": round(worst[k + "_ms"], 5)}
         dominant = max(("transform", "setup", "bin", "raster", "shade"), key=lambda k: mean[k + "_ms"])
-        tj = {}
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes and VALU instructions per launch from rocprofv3 PMC passes
+        # HBM bytes and VALU instructions per launch from rocprofv3 PMC passes of THIS workload (tools/profile_set.sh ->
+        # profiles/traffic_<workload>.json).  The file names the sha256 of the kernel source it was measured on; when that is
+        # not the tree's, the counters describe other kernels and are left out of the line.
+        tj, traffic_note = {}, None
+        tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
+                sha = hashlib.sha256(open(os.path.join(ROOT, "renderer_amd", "csrc", "kernels.hip"), "rb").read()).hexdigest()
                 if tj.get("workload") != args.workload or tj.get("n_gpus", 1) != world:
-                    tj = {}
+                    tj, traffic_note = {}, "no PMC passes of this workload and GPU count"
+                elif tj.get("kernels_sha256") != sha:
+                    tj, traffic_note = {}, f"profiles/traffic_{args.workload}.json was measured on another kernels.hip: traffic and valu counters dropped"
             except Exception:
-                tj = {}
+                tj, traffic_note = {}, "unreadable traffic file"
+        else:
+            traffic_note = "no PMC passes of this workload under profiles/"
 
         def roofline_of(k):
             ach = kernels[k]["gbps"]
@@ -338,9 +361,12 @@ def main():
                  "frac": round(ach / HBM_PEAK_GBS, 4) if ach else None, "traffic": tj.get("kernels", {}).get(k)}
             insts = tj.get("valu_insts", {}).get(k)
             if insts and mean[k + "_ms"] > 0:
-                # share of the SIMDs' cycles spent on VALU instructions (2 cycles each; 4, the figure of the 16-lane
-                # SIMDs before gfx950, would put k_shade's 103.6 M instructions at 103 % of its own duration)
-                r["valu_busy"] = round(insts * 2 / (N_SIMDS * VALU_CLOCK_HZ * mean[k + "_ms"] * 1e-3), 3)
+                # the VALU issue bound beside the HBM one: a wave64 VALU instruction takes a SIMD at least 2 cycles
+                # (MI355X_MICROARCH.md; measured 2.25 for plain f32, 4.2 for the other classes: profiles/r02_valu_ops_microbench.txt),
+                # so instructions x 2 cycles / (SIMDs x clock) is the least time the kernel's VALU work takes
+                floor_ms = insts * 2 / (N_SIMDS * VALU_CLOCK_HZ) * 1e3
+                r["roofline_valu"] = {"bound": "valu_issue", "insts_per_launch": insts, "floor_ms": round(floor_ms, 5),
+                                      "frac": round(floor_ms / mean[k + "_ms"], 3)}
             return r
         result = {
             "metric": "Mtriangles/s", "value": round(n_tris * fps / 1e6, 2), "unit": "Mtriangles/s",
@@ -359,8 +385,10 @@ def main():
             # small-triangle path inside k_setup (k_raster has no bin entries), so that kernel is reported too
             "roofline_setup": roofline_of("setup"),
             "roofline_raster": roofline_of("raster"),
+            "traffic_note": traffic_note,
             "kernels": kernels,
             "dropped_frames": driver.dropped,
+            "frame_check": frame_check,
             "gpu_frame_ms": round(mean["frame_ms"], 4), "timed_frames": n_frames, "settle_frames_before_kernel_timing": settle,
             "frame_stats": stats,
         }
@@ -371,6 +399,45 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return result
+
+
+def check_assembled_frame(vs, scene_all, sort_last, strips, pending_last, rank, local_rank):
+    """After the timed loop, outside `elapsed`: rank 0 renders the same frame alone (no partition, every instance) and
+    compares it with the frame the ranks assembled — equal bits for the sort-first gather; for the sort-last composite
+    equal depth bits everywhere and equal colours except where two shards tie in depth (there the composite takes the
+    smaller colour word, a single GPU the first drawn).  Returns "ok ..." or a description of the difference (rank 0),
+    None on the other ranks."""
+    if rank != 0:
+        return None
+    import torch
+    from renderer_amd import VisualServer
+    from renderer_amd.sort_first import unpack_numpy
+    alone = VisualServer(scene_all.width, scene_all.height, device=local_rank)
+    scene_all.populate(alone)
+    if sort_last:
+        ptr, nbytes = alone.packed_device_ptr()          # (renders the frame with the packed output on)
+        n = scene_all.width * scene_all.height
+        single = torch.empty(n, dtype=torch.int64, device="cuda")
+        hip = C.CDLL("libamdhip64.so")
+        assert hip.hipMemcpy(C.c_void_p(single.data_ptr()), C.c_void_p(ptr), C.c_size_t(n * 8), 3) == 0
+        got = pending_last[0].view(-1)[:n]
+        torch.cuda.synchronize()
+        d_single, c_single = unpack_numpy(single.cpu().numpy())
+        d_got, c_got = unpack_numpy(got.cpu().numpy())
+        alone.close()
+        if not (d_single.view(np.uint32) == d_got.view(np.uint32)).all():
+            return f"depth differs on {(d_single.view(np.uint32) != d_got.view(np.uint32)).sum()} pixels"
+        ties = int((c_single != c_got).any(axis=-1).sum())
+        if ties > 1e-4 * n:
+            return f"colour differs on {ties} pixels of equal depth"
+        return f"ok (depth bits equal, {ties} pixels where shards tie in depth)"
+    alone.render()
+    want = alone.read_color_rgba8()
+    alone.close()
+    got = vs.read_color_rgba8()
+    if not (got == want).all():
+        return f"colour differs on {(got != want).any(axis=-1).sum()} pixels"
+    return "ok (equal bits)"
 
 
 def cpu_baseline(scene, desc, threads):

@@ -152,6 +152,11 @@ struct SetupRecord {
 static_assert(sizeof(SetupRecord) == 48, "SetupRecord is 3 x 16 bytes");
 
 // Device-side counters of one frame.
+// Statistics of k_setup's workgroups (triangles that survived setup in the low half, bbox pixels of the triangles
+// rasterized at setup in the high half of one 64-bit word), striped over kStatStripes words that each sit in a cache
+// line of their own: the L2 serializes atomics per LINE (~88 per microsecond), so 32 words next to each other cost
+// k_setup 60 % at C3, 32 lines nothing measurable.  One block of kStatStripes * kStatStride words per counter set.
+constexpr uint32_t kStatStripes = 32, kStatStride = 16;
 // A vertex after K1's viewport transform and snap (raster rule 4), with its clip-space verdicts, so that
 // K2a's per-triangle work starts from integers: each vertex is shared by about six triangles.
 struct SnapVert {

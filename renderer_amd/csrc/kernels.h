@@ -45,12 +45,13 @@ struct FrameBuffers {
     SetupRecord* records;
     uint2* tilewords;               // per record: .x = tx0 | ty0<<8 | (w-1)<<16 | (h-1)<<24, .y = position in its bin (single-tile records)
     uint32_t* clip_queue;           // triangle ids that need the clipper
-    uint32_t* chunk_count;          // per k_setup workgroup: [0,U) records it wrote, [U,2U) triangles that survived setup, [2U,3U) bbox pixels of its small triangles (U = n_units)
+    uint32_t* chunk_count;          // per k_setup workgroup (work unit): record slots it used
     uint32_t* tile_count;           // [0,T): single-tile records per tile; [T,2T): multi-tile records per tile
     uint32_t* tile_offset;          // per tile, exclusive scan of tile_count
     uint32_t* tile_cursor;          // per tile, fill cursor of the multi-tile records
     uint32_t* entries;              // bin entries: record slots, grouped by tile
     FrameCounters* counters;
+    unsigned long long* stat_stripes;     // this pass's kStatStripes * kStatStride words (device_types.h)
     const FrameCounters* main_counters;   // the main pass's counter set (k_shade reports its fragment count)
     uint32_t no_chain;              // the frame is launched without k_clip .. k_raster (a run of frames needed none of them): k_shade sums the statistics and withholds the frame if it did need them
     uint32_t early_z;               // launch the plain main pass's k_setup with the depth test before the atomic (frames with depth complexity)

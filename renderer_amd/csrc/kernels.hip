@@ -211,6 +211,7 @@ __global__ __launch_bounds__(256) void k_clear(FrameBuffers fb, uint32_t n_count
     for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n_counts; k += gridDim.x * 256u) fb.tile_count[k] = 0;
     for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n_vblocks; k += gridDim.x * 256u) fb.vblock_needed[k] = 0;
     if (blockIdx.x == 0 && threadIdx.x < sizeof(FrameCounters) / 4) reinterpret_cast<uint32_t*>(fb.counters)[threadIdx.x] = 0;
+    if (blockIdx.x == 0) for (uint32_t k = threadIdx.x; k < kStatStripes * kStatStride; k += 256u) fb.stat_stripes[k] = 0ull;
 }
 
 // Work-unit culling: one thread per (draw item, chunk).  The chunk's object-space box is taken
@@ -1058,8 +1059,9 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
     __syncthreads();
     if (threadIdx.x == 0) {
         fb.chunk_count[unit_index] = s_used;
-        fb.chunk_count[fc.n_units + unit_index] = s_valid[0] + s_valid[1] + s_valid[2] + s_valid[3];
-        fb.chunk_count[2u * fc.n_units + unit_index] = s_frags[0] + s_frags[1] + s_frags[2] + s_frags[3];
+        // (striped: one word would take ten to a hundred thousand atomics per frame, at ~88 per microsecond)
+        const uint32_t v = s_valid[0] + s_valid[1] + s_valid[2] + s_valid[3], f = s_frags[0] + s_frags[1] + s_frags[2] + s_frags[3];
+        if (v | f) atomicAdd(&fb.stat_stripes[(unit_index % kStatStripes) * kStatStride], (unsigned long long)v | ((unsigned long long)f << 32));
     }
 }
 
@@ -1205,18 +1207,17 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(FrameBuffers fb, Capacities
     const uint32_t n_active = min(fb.counters->n_active, fc.n_units);
     const uint32_t n_wide = min(fb.counters->n_wide, cap.wide_list);
     uint32_t v = 0, used = 0;
-    unsigned long long fr = 0;          // covered samples of the direct path (depth complexity, for the host)
+    unsigned long long fr = 0;          // bbox pixels of the direct path's triangles (depth complexity, for the host)
+    if (tid < kStatStripes) { const unsigned long long w = fb.stat_stripes[tid * kStatStride]; v = (uint32_t)w; fr = w >> 32; }
     for (uint32_t c0 = 0; c0 < n_active; c0 += 8u * 1024u) {
-        uint32_t part[8], slots[8], frags[8];
+        uint32_t slots[8];
 #pragma unroll
         for (uint32_t k = 0; k < 8; ++k) {          // independent loads in flight, not a chain of round trips
             const uint32_t c = c0 + k * 1024u + tid;
-            part[k] = c < n_active ? fb.chunk_count[fc.n_units + c] : 0u;
             slots[k] = c < n_active ? fb.chunk_count[c] : 0u;
-            frags[k] = c < n_active ? fb.chunk_count[2u * fc.n_units + c] : 0u;
         }
 #pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) { v += part[k]; used |= slots[k]; fr += frags[k]; }
+        for (uint32_t k = 0; k < 8; ++k) used |= slots[k];
     }
     // A pass in which no unit wrote a record and the clipper wrote none either (every triangle took k_setup's direct path:
     // C3, C5, the depth-only passes of such scenes) has no tile counts to scan: k_bin_fill and k_raster look at
@@ -2250,18 +2251,12 @@ __global__ __launch_bounds__(256, kShadows ? (kSamples > 1 ? 1 : 5) : (kSamples 
         if (blockIdx.x == 0 && fb.report) {
             uint32_t frags = ((cptr_counters)fb.main_counters)->n_fragments;       // (the main pass's: the host picks its k_setup variant by it)
             if (fb.no_chain) {
-                // k_scan_tiles did not run: the main pass's statistics are summed here, by this one workgroup
-                __shared__ unsigned long long s_sum[2];
-                if (tid == 0) { s_sum[0] = 0ull; s_sum[1] = 0ull; }
-                __syncthreads();
-                const uint32_t n_units = fc.n_units, n_active = min(((cptr_counters)fb.main_counters)->n_active, n_units);
+                // k_scan_tiles did not run: the main pass's statistics are summed here (scalar loads of the stripes)
+                typedef const __attribute__((address_space(4))) unsigned long long* cptr_u64;
                 unsigned long long v = 0, fr = 0;
-                for (uint32_t c = tid; c < n_active; c += 256u) { v += fb.chunk_count[n_units + c]; fr += fb.chunk_count[2u * n_units + c]; }
-                for (int o = 32; o > 0; o >>= 1) { v += __shfl_xor(v, o); fr += __shfl_xor(fr, o); }
-                if (lane == 0) { atomicAdd(&s_sum[0], v); atomicAdd(&s_sum[1], fr); }
-                __syncthreads();
-                frags = (uint32_t)min(s_sum[1], 0xFFFFFFFFull);
-                if (tid == 0) { fb.counters->n_valid = (uint32_t)min(s_sum[0], 0xFFFFFFFFull); fb.counters->n_fragments = frags; }
+                for (uint32_t k = 0; k < kStatStripes; ++k) { const unsigned long long w = ((cptr_u64)fb.stat_stripes)[k * kStatStride]; v += w & 0xFFFFFFFFull; fr += w >> 32; }
+                frags = (uint32_t)min(fr, 0xFFFFFFFFull);
+                if (tid == 0) { fb.counters->n_valid = (uint32_t)min(v, 0xFFFFFFFFull); fb.counters->n_fragments = frags; }
             }
             if (tid == 0) {
                 volatile FrameReport* r = fb.report;

@@ -144,9 +144,9 @@ VisualServer::~VisualServer() {
     shade_profile_dump();
     for (auto& kv : meshes_)
         for (auto& s : kv.second.submeshes) { s.vertex_buffer.release(); s.positions.release(); s.index_buffer.release(); s.chunks.release(); }
-    for (int k = 0; k < 2; ++k) { d_tables_[k].release(); d_clip_[k].release(); d_vis_[k].release(); d_counters_[k].release(); }
+    for (int k = 0; k < 2; ++k) { d_tables_[k].release(); d_clip_[k].release(); d_vis_[k].release(); d_counters_[k].release(); d_stat_stripes_[k].release(); }
     d_snap_.release(); d_hiz_.release(); d_wide_list_.release(); d_tile_slices_.release(); d_raster_extra_.release();
-    d_records_.release(); d_tilewords_.release(); d_clip_queue_.release(); d_chunk_count_[0].release(); d_chunk_count_[1].release(); d_vblock_needed_.release(); d_active_units_.release(); d_tile_count_.release();
+    d_records_.release(); d_tilewords_.release(); d_clip_queue_.release(); d_chunk_count_.release(); d_vblock_needed_.release(); d_active_units_.release(); d_tile_count_.release();
     d_tile_offset_.release(); d_tile_cursor_.release(); d_entries_.release();
     for (auto& kv : textures_) kv.second.texels.release();
     d_textures_.release();
@@ -843,11 +843,11 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     struct {
         float4* clip; SnapVert* snap; SetupRecord* records; uint32_t *tilewords, *clip_queue, *chunk_count, *active_units, *vblock_needed, *entries,
             *wide_list, *tile_slices, *tile_count, *tile_offset, *tile_cursor;
-        uint2* raster_extra; FrameCounters* counters; uint64_t* vis; float* hiz;
+        uint2* raster_extra; FrameCounters* counters; uint64_t* vis; float* hiz; unsigned long long* stripes;
     } bp{};
     const size_t n_vblocks = ((size_t)fc.n_verts / kVertexBlock + 2) * n_views_max;
     const size_t n_unit_words = std::max<size_t>(2 * (size_t)fc.n_units * n_views_max, 2);
-    const size_t n_count_words = std::max<size_t>(3 * (size_t)fc.n_units * n_views_max, 3);      // per unit: record slots used, triangles that survived, covered samples
+    const size_t n_count_words = std::max<size_t>((size_t)fc.n_units * n_views_max, 1);          // per unit: record slots used
     const size_t n_view_verts = std::max<size_t>((size_t)fc.n_verts * n_views_max, 1);
     // Whether K1 keeps the clip positions for the shading kernel or that kernel makes them again from the corners' vertices
     // (kernels.hip, corner_clip: the same bits either way).  Storing costs K1 16 of its 44 bytes per vertex (1.45 us per
@@ -873,6 +873,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         bp.raster_extra = arena.take<uint2>(kRasterExtraCap);
         bp.tile_count = arena.take<uint32_t>(2 * n_tiles); bp.tile_offset = arena.take<uint32_t>(n_tiles); bp.tile_cursor = arena.take<uint32_t>(n_tiles);
         bp.counters = arena.take<FrameCounters>(n_counter_sets);
+        bp.stripes = arena.take<unsigned long long>((size_t)n_counter_sets * kStatStripes * kStatStride);
         bp.vis = arena.take<uint64_t>(n_tiles * kTilePixels * msaa_);
         bp.hiz = early_z_frame_ ? arena.take<float>(n_tiles * 16) : nullptr;
     } else {
@@ -880,7 +881,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         d_snap_.ensure(n_view_verts);
         d_records_.ensure(cap_.records); d_tilewords_.ensure(2 * (size_t)cap_.records);
         d_clip_queue_.ensure(2 * (size_t)cap_.clip_queue);
-        d_chunk_count_[p].ensure(n_count_words);       // (by frame parity: a frame without the record chain has its statistics summed by its shading kernel)
+        d_chunk_count_.ensure(n_count_words);
         d_active_units_.ensure(n_unit_words);
         d_vblock_needed_.ensure(n_vblocks);
         d_entries_.ensure(cap_.entries);
@@ -891,10 +892,12 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         if (want_packed_) d_packed_.ensure((size_t)width_ * height_);
         if (want_hdr) d_hdr_.ensure((size_t)width_ * height_ * 3);
         bp.clip = store_clip && store_clip_fits ? d_clip_[p].ptr : nullptr; bp.snap = d_snap_.ptr; bp.records = d_records_.ptr; bp.tilewords = d_tilewords_.ptr; bp.clip_queue = d_clip_queue_.ptr;
-        bp.chunk_count = d_chunk_count_[p].ptr; bp.active_units = d_active_units_.ptr; bp.vblock_needed = d_vblock_needed_.ptr; bp.entries = d_entries_.ptr;
+        bp.chunk_count = d_chunk_count_.ptr; bp.active_units = d_active_units_.ptr; bp.vblock_needed = d_vblock_needed_.ptr; bp.entries = d_entries_.ptr;
         bp.wide_list = d_wide_list_.ptr; bp.tile_slices = d_tile_slices_.ptr; bp.raster_extra = d_raster_extra_.ptr;
         bp.tile_count = d_tile_count_.ptr; bp.tile_offset = d_tile_offset_.ptr; bp.tile_cursor = d_tile_cursor_.ptr;
         bp.counters = d_counters_[p].ptr; bp.vis = d_vis_[p].ptr;
+        d_stat_stripes_[p].ensure((size_t)n_counter_sets * kStatStripes * kStatStride);
+        bp.stripes = reinterpret_cast<unsigned long long*>(d_stat_stripes_[p].ptr);
         if (early_z_frame_) d_hiz_.ensure(n_tiles * 16);
         bp.hiz = d_hiz_.ptr;
     }
@@ -1017,7 +1020,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     fb.unit_bases = reinterpret_cast<const uint32_t*>(tb + off_ub); fb.active_units = reinterpret_cast<uint2*>(bp.active_units); fb.vblock_needed = bp.vblock_needed;
     fb.tile_count = bp.tile_count; fb.tile_offset = bp.tile_offset; fb.tile_cursor = bp.tile_cursor;
     fb.wide_list = bp.wide_list; fb.tile_slices = bp.tile_slices; fb.raster_extra = bp.raster_extra;
-    fb.entries = bp.entries; fb.counters = bp.counters; fb.main_counters = bp.counters;
+    fb.entries = bp.entries; fb.counters = bp.counters; fb.main_counters = bp.counters; fb.stat_stripes = bp.stripes;
     // without the record chain: after a run of frames that needed none of it (never the no-allocation frame, whose
     // statistics nobody could sum: its chunk counts live in the shared array)
     frame_no_chain_ = allow_no_chain_ && !noalloc && full_chain_frames_ == 0 && chain_free_streak_ >= kNoChainStreak;
@@ -1111,6 +1114,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         sfb.items = reinterpret_cast<const DrawItem*>(tb + off_si); sfb.lights = nullptr; sfb.shadow_sets = nullptr; sfb.alpha_test = 0;
         sfb.clip = nullptr;        // depth only: nothing reads clip positions (k_transform skips the store)
         sfb.counters = bp.counters + 1 + k;
+        sfb.stat_stripes = bp.stripes + (size_t)(1 + k) * kStatStripes * kStatStride;
         sfb.launch_order = order.ptr; sfb.n_owned = n_order;
         sfb.vis = shadow_layers_[p][k].ptr;         // the four layers, contiguous: the stacked target's tiles
         sfb.frame_rgba8 = nullptr; sfb.tiles_rgba8 = nullptr; sfb.packed = nullptr; sfb.hdr = nullptr;
@@ -1472,6 +1476,7 @@ void VisualServer::detile_gathered(uint32_t world, const void* dev_gathered, uin
     fc.width = width_; fc.height = height_; fc.tiles_x = tiles_x_; fc.tiles_y = tiles_y_;
     launch_detile_gathered(static_cast<const uint8_t*>(dev_gathered), stride_bytes, world, fc, d_frame_.ptr, stream_);
     HIP_CHECK(hipGetLastError());
+    assembled_frame_ = true; have_frame_ = true;       // read-backs hand out the assembled frame until the next render
 }
 
 void VisualServer::packed_device_ptr(void** p, uint64_t* bytes) {
@@ -1495,6 +1500,7 @@ void VisualServer::unpack(const void* dev_packed) {
     HIP_CHECK(hipGetLastError());      // (stream-ordered: read-backs and rnd_finish wait on the same stream)
     have_frame_ = true;
     last_frame_out_ = d_frame_.ptr;
+    assembled_frame_ = true;
 }
 
 void VisualServer::set_packed_output(void* dev_ptr, uint64_t bytes) {

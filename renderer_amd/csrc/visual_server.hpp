@@ -254,7 +254,7 @@ private:
     DeviceBuffer<float4> d_clip_[2];
     DeviceBuffer<SnapVert> d_snap_;
     DeviceBuffer<SetupRecord> d_records_;
-    DeviceBuffer<uint32_t> d_tilewords_, d_clip_queue_, d_chunk_count_[2], d_vblock_needed_, d_active_units_, d_tile_count_, d_tile_offset_, d_tile_cursor_, d_entries_;
+    DeviceBuffer<uint32_t> d_tilewords_, d_clip_queue_, d_chunk_count_, d_vblock_needed_, d_active_units_, d_tile_count_, d_tile_offset_, d_tile_cursor_, d_entries_;
     DeviceBuffer<FrameCounters> d_counters_[2];     // [0] main pass, then one per shadow pass
     uint32_t n_counter_sets_ = 1, h_counter_sets_ = 0;
     // shadow cascades of the directional lights
@@ -332,6 +332,7 @@ private:
     void note_chain(bool needed, bool failed);
     bool assembled_frame_ = false;              // d_frame_ holds a frame assembled from every rank (gather_tiles / composite_packed), until the next render
     uint32_t split_units_ = 0;                  // units of the early-depth variant's first pass (build_frame)
+    DeviceBuffer<uint64_t> d_stat_stripes_[2];  // k_setup's striped statistics, one block per counter set (by frame parity, as the counters)
     DeviceBuffer<float> d_hiz_;                 // farthest depth per 8x8 block between its two passes
     void note_depth_complexity(uint64_t n_fragments);
     std::vector<GpuLight> gpu_lights_;
