@@ -2251,10 +2251,18 @@ __global__ __launch_bounds__(256, kShadows ? (kSamples > 1 ? 1 : 5) : (kSamples 
         if (blockIdx.x == 0 && fb.report) {
             uint32_t frags = ((cptr_counters)fb.main_counters)->n_fragments;       // (the main pass's: the host picks its k_setup variant by it)
             if (fb.no_chain) {
-                // k_scan_tiles did not run: the main pass's statistics are summed here (scalar loads of the stripes)
-                typedef const __attribute__((address_space(4))) unsigned long long* cptr_u64;
-                unsigned long long v = 0, fr = 0;
-                for (uint32_t k = 0; k < kStatStripes; ++k) { const unsigned long long w = ((cptr_u64)fb.stat_stripes)[k * kStatStride]; v += w & 0xFFFFFFFFull; fr += w >> 32; }
+                // k_scan_tiles did not run: the main pass's statistics are summed here, one stripe per lane of the first
+                // wave (vector loads on purpose: the compiler hoists scalar loads of constant-address-space pointers
+                // above the branch, and then every workgroup of the grid pays for 32 cache lines: +17 us at C3)
+                __shared__ unsigned long long s_sum[2];
+                if (tid < 64u) {
+                    const unsigned long long w = tid < kStatStripes ? __builtin_nontemporal_load(&fb.stat_stripes[tid * kStatStride]) : 0ull;
+                    unsigned long long v = w & 0xFFFFFFFFull, fr = w >> 32;
+                    for (int o = 32; o > 0; o >>= 1) { v += __shfl_xor(v, o); fr += __shfl_xor(fr, o); }
+                    if (tid == 0) { s_sum[0] = v; s_sum[1] = fr; }
+                }
+                __syncthreads();
+                const unsigned long long v = s_sum[0], fr = s_sum[1];
                 frags = (uint32_t)min(fr, 0xFFFFFFFFull);
                 if (tid == 0) { fb.counters->n_valid = (uint32_t)min(v, 0xFFFFFFFFull); fb.counters->n_fragments = frags; }
             }
