@@ -7,19 +7,29 @@ FETCH_SIZE reads half of the bytes fetched: MI355X_MICROARCH.md, HBM section; ch
 """
 import ast, hashlib, json, os, sys
 
-KEYS = {"k_clear": "clear", "k_cull": "cull", "k_transform": "transform", "k_setup": "setup", "k_clip": "clip",
+KEYS = {"k_clear": "clear", "k_cull": "cull", "k_transform": "transform", "k_setup": "setup", "k_hiz": "setup", "k_clip": "clip",
         "k_scan_tiles": "scan", "k_bin_fill": "bin", "k_raster": "raster", "k_shade": "shade"}
 
 
 def read(path):
-    out = {}
+    """Per FRAME: every dispatch of every variant of a kernel (the two passes of the early-depth k_setup and the k_hiz
+    between them included, as bench.py times them: events around the whole launch_setup), summed over the run and
+    divided by the run's frames (= dispatches of k_shade).  The first frames of a C4 run, before the host has switched
+    the early-depth variant on, are part of that mean (2 to 4 of ~216)."""
+    total, frames = {}, 0
     for line in open(path):
         name, _, rest = line.partition(" {")
-        body = "{" + rest.rsplit("}", 1)[0] + "}"
+        body, _, tail = rest.rpartition("}")
+        n = int(tail.split()[-1])
+        vals = ast.literal_eval("{" + body + "}")
         for k, short in KEYS.items():
-            if "rnd::" + k in name:
-                out[short] = ast.literal_eval(body)
-    return out
+            if "rnd::" + k + "<" in name + "<" or ("rnd::" + k) == name.strip():
+                acc = total.setdefault(short, {})
+                for c, v in vals.items():
+                    acc[c] = acc.get(c, 0.0) + v * n
+                if k == "k_shade":
+                    frames += n
+    return {k: {c: v / max(frames, 1) for c, v in acc.items()} for k, acc in total.items()}
 
 
 fetch, write, sq, tag = read(sys.argv[1]), read(sys.argv[2]), read(sys.argv[3]), sys.argv[4]
@@ -32,8 +42,8 @@ json.dump({
     "workload": workload, "n_gpus": 1,
     "kernels_sha256": sha,      # of renderer_amd/csrc/kernels.hip when the passes ran: bench.py drops the counters when the tree's differs
     "source": f"rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE and --pmc SQ_INSTS_VALU ... in separate runs (tools/profile_pmc.sh; "
-              f"summaries profiles/{tag}_pmc_fetch_{workload}.txt, {tag}_pmc_write_{workload}.txt, {tag}_pmc_sq_{workload}.txt), mean per launch over the frames of bench.py --workload {workload}",
+              f"summaries profiles/{tag}_pmc_fetch_{workload}.txt, {tag}_pmc_write_{workload}.txt, {tag}_pmc_sq_{workload}.txt), mean per frame over the frames of bench.py --workload {workload}",
     "correction": "gfx950: FETCH_SIZE (KB) reads 1/2 of the bytes fetched (MI355X_MICROARCH.md, HBM): bytes = 2*FETCH_SIZE*1000 + WRITE_SIZE*1000",
-    "grouping": "one entry per kernel, as bench.py times them (k_clear, k_cull, k_transform, k_setup, k_clip, k_scan_tiles, k_bin_fill, k_raster, k_shade)",
+    "grouping": "per frame, one entry per kernel as bench.py times them (k_clear, k_cull, k_transform, k_setup incl. its two early-depth passes and k_hiz, k_clip, k_scan_tiles, k_bin_fill, k_raster, k_shade); all passes of a frame summed",
     "kernels": kernels, "valu_insts": valu}, open(os.path.join(ROOT, "profiles", f"traffic_{workload}.json"), "w"), indent=2)
 print(json.dumps({"kernels": kernels, "valu_insts": valu}, indent=1))
