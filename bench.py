@@ -110,24 +110,35 @@ class FrameDriver:
             raise RuntimeError("frame failed: " + (api.last_error(ctx) or b"").decode())
 
 
-def algorithmic_bytes(stats, n_visible_tris):
-    """Per-frame algorithmic HBM bytes of each kernel (DESIGN.md "Kernels")."""
+def algorithmic_bytes(stats, n_visible_tris, scene=None):
+    """Per-frame algorithmic HBM bytes of each kernel (DESIGN.md "Kernels").
+
+    Source data (positions, indices, vertices) is counted once per DISTINCT mesh the frame draws: the instances of one
+    mesh (C5: 1000 of one 100 k-triangle sphere) read the same 1.8 MB, which no cache-less machine model needs to fetch
+    1000 times; what is per instance is what the frame writes and reads back (snapped vertices, clip positions)."""
     nv, nt = stats["n_vertices"], stats["n_triangles"]
     nrec, nbin, p = stats["n_setup"], stats["n_bin_entries"], stats["n_pixels"]
+    src_nv, src_nt = nv, nt
+    if scene is not None:
+        used = sorted({int(m) for _, _, m in scene.instances})
+        src_nv = min(nv, sum(len(sm.vertices) for m in used for sm in scene.meshes[m].submeshes))
+        src_nt = min(nt, sum(len(sm.indices) // 3 for m in used for sm in scene.meshes[m].submeshes))
+    keeps_clip = 2 * nv <= 3 * p                               # the host's per-frame rule (visual_server.cpp, store_clip)
+    corners = min(3 * n_visible_tris, nv)
     return {
         "clear": 8 * p,                                        # visibility words of the owned tiles
-        # SoA positions in, clip xyzw and the snapped vertex (x, y, z/w, outcodes) out
-        "transform": 12 * nv + 16 * nv + 16 * nv,
+        # SoA positions in, the snapped vertex (x, y, z/w, outcodes) and — in frames that keep them — clip xyzw out
+        "transform": 12 * src_nv + 16 * nv + (16 * nv if keeps_clip else 0),
         # indices, each snapped vertex once, one 8-byte visibility word per pixel (direct small-triangle
         # path), and for the triangles that go through the bins a 48-byte record + (tile word, bin pos)
-        "setup": 12 * nt + 16 * nv + 8 * p + 56 * min(nbin, nrec),
+        "setup": 12 * src_nt + 16 * nv + 8 * p + 56 * min(nbin, nrec),
         "bin": 12 * min(nbin, nrec) + 4 * nbin,               # (tile word, bin pos) + tile offset in, bin entries out
         "raster": 52 * nbin + 16 * min(p, 1024 * nbin),       # entries + records per bin entry, visibility tile in and out
         # vis in, rgba8 out, gathers: SURVEY.md 8d's K4 figure — the index triple per visible triangle and, per distinct
-        # corner, the 32-byte source vertex + the 16-byte clip position.  (Since round 2 the kernel needs only 28 of
-        # those 48 bytes — clip position + normal; the world position comes from the clip coordinates — but the vertex's
-        # 12 normal bytes still arrive in its whole cache line: the PMC traffic is unchanged, DESIGN.md 5.)
-        "shade": 8 * p + 4 * p + 12 * n_visible_tris + 48 * min(3 * n_visible_tris, nv),
+        # corner, the 32-byte source vertex + the 16-byte clip position (the latter only in frames that keep it; the
+        # kernel makes it again from the vertex otherwise).  (Since round 2 the kernel needs only 28 of those 48 bytes —
+        # clip position + normal — but the vertex's 12 normal bytes still arrive in its whole cache line, DESIGN.md 5.)
+        "shade": 8 * p + 4 * p + 12 * min(n_visible_tris, src_nt) + 32 * min(corners, src_nv) + (16 * corners if keeps_clip else 0),
     }
 
 
@@ -328,7 +339,7 @@ def main():
         n_visible = int(np.unique(ids).size - 1) if ids is not None else stats["n_setup"]
         if ids is not None and not (ids != 0xFFFFFFFF).any():
             raise SystemExit("bench frame is empty: refusing to report a number")
-        alg = algorithmic_bytes(stats, n_visible)
+        alg = algorithmic_bytes(stats, n_visible, scene)
         kernels = {}
         for k in ("clear", "transform", "setup", "bin", "raster", "shade"):
             ms = mean[k + "_ms"]

@@ -903,6 +903,33 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
     uint32_t valid = 0, frags = 0;      // (frags: per lane, summed at the end)
     // (a unit without triangles or with tables that do not fit runs no iteration; the loads below need nv >= 1)
     const uint32_t n_iters = (tables_ok && nv != 0u) ? (n_here + 255u) / 256u : 0u;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    // RND_SETUP_PIPE 1: the next iteration's index triple is requested before this iteration's vertices (C5 setup 0.686 ->
+    // 0.654 ms, C3 0.103 -> 0.101); 2: its vertices too (91 VGPRs, five waves per SIMD instead of seven: C5 0.723, C3 0.110)
+#ifndef RND_SETUP_PIPE
+#define RND_SETUP_PIPE 1
+#endif
+    // straight-line: a lane beyond the chunk's end works on the chunk's first triangle, an index beyond the
+    // item's vertices is clamped and reported; both are dropped by the predicate
+    auto index_ptr = [&](uint32_t iter) {
+        const uint32_t local = iter * 256u + threadIdx.x;
+        return indices + 3ull * (first_t + (local < n_here ? local : 0u));
+    };
+#if RND_SETUP_PIPE >= 1
+    uint32_t ni0 = 0, ni1 = 0, ni2 = 0;         // the next iteration's index triple, in flight while this one is worked on
+    if (n_iters) { gptr_u32 ix = index_ptr(0); ni0 = ix[0]; ni1 = ix[1]; ni2 = ix[2]; }
+#endif
+#if RND_SETUP_PIPE >= 2
+    u32x4 nq0 = {}, nq1 = {}, nq2 = {};          // ... and its three snapped vertices
+    bool n_ok = false;
+    if (n_iters) {
+        n_ok = max(ni0, max(ni1, ni2)) < nv;
+        nq0 = *reinterpret_cast<const u32x4*>(snap_v + vb + min(ni0, nv - 1u));
+        nq1 = *reinterpret_cast<const u32x4*>(snap_v + vb + min(ni1, nv - 1u));
+        nq2 = *reinterpret_cast<const u32x4*>(snap_v + vb + min(ni2, nv - 1u));
+        if (n_iters > 1u) { gptr_u32 ix = index_ptr(1); ni0 = ix[0]; ni1 = ix[1]; ni2 = ix[2]; }
+    }
+#endif
     for (uint32_t iter = 0; iter < n_iters; ++iter) {
         const uint32_t local = iter * 256u + threadIdx.x;
         const uint32_t gid = tri_base + first_t + local;                   // draw-order triangle id
@@ -911,21 +938,37 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
         SetupRecord rec;
         TileRect tr;
         {
-            // straight-line: a lane beyond the chunk's end works on the chunk's first triangle, an index beyond the
-            // item's vertices is clamped and reported; both are dropped by the predicate
             const bool in = local < n_here;
-            gptr_u32 ix = indices + 3ull * (first_t + (in ? local : 0u));
+#if RND_SETUP_PIPE >= 2
+            u32x4 q0 = nq0, q1 = nq1, q2 = nq2;
+            const bool idx_ok = n_ok;
+            asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2));
+            if (iter + 1u < n_iters) {
+                n_ok = max(ni0, max(ni1, ni2)) < nv;
+                nq0 = *reinterpret_cast<const u32x4*>(snap_v + vb + min(ni0, nv - 1u));
+                nq1 = *reinterpret_cast<const u32x4*>(snap_v + vb + min(ni1, nv - 1u));
+                nq2 = *reinterpret_cast<const u32x4*>(snap_v + vb + min(ni2, nv - 1u));
+                if (iter + 2u < n_iters) { gptr_u32 ix = index_ptr(iter + 2u); ni0 = ix[0]; ni1 = ix[1]; ni2 = ix[2]; }
+            }
+            guard(idx_ok, fb.counters, kGuardSetup);
+#else
+#if RND_SETUP_PIPE == 1
+            uint32_t i0 = ni0, i1 = ni1, i2 = ni2;
+            if (iter + 1u < n_iters) { gptr_u32 ix = index_ptr(iter + 1u); ni0 = ix[0]; ni1 = ix[1]; ni2 = ix[2]; }
+#else
+            gptr_u32 ix = index_ptr(iter);
             uint32_t i0 = ix[0], i1 = ix[1], i2 = ix[2];
+#endif
             const bool idx_ok = max(i0, max(i1, i2)) < nv;
             guard(idx_ok, fb.counters, kGuardSetup);
             i0 = min(i0, nv - 1u); i1 = min(i1, nv - 1u); i2 = min(i2, nv - 1u);
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             u32x4 q0 = *reinterpret_cast<const u32x4*>(snap_v + vb + i0);
             u32x4 q1 = *reinterpret_cast<const u32x4*>(snap_v + vb + i1);
             u32x4 q2 = *reinterpret_cast<const u32x4*>(snap_v + vb + i2);
             // three whole 16-byte gathers in one round trip: left alone the compiler loads the outcodes
             // first and sinks the positions into the branch that uses them (six gathers, two round trips)
             asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2));
+#endif
             const SnapVert v0{(int32_t)q0.x, (int32_t)q0.y, __uint_as_float(q0.z), q0.w};
             const SnapVert v1{(int32_t)q1.x, (int32_t)q1.y, __uint_as_float(q1.z), q1.w};
             const SnapVert v2{(int32_t)q2.x, (int32_t)q2.y, __uint_as_float(q2.z), q2.w};

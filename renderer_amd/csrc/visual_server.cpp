@@ -734,6 +734,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     const bool noalloc = noalloc_out != nullptr;
     static const bool prof = std::getenv("RND_HOST_PROFILE") != nullptr;
     static double acc[6]; static uint32_t acc_n;
+    static double sub[6];       // inside the launches: waits, geometry launches, hand-over events, shading launch, end events
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto t_start = now(); auto t_prev = t_start;
     auto lap = [&](int k) { if (prof) { auto t = now(); acc[k] += std::chrono::duration<double, std::micro>(t - t_prev).count(); t_prev = t; } };
@@ -1076,8 +1077,11 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         timed_set = &es;
     }
     auto mark = [&](int k, hipStream_t on) { if (ev_) HIP_CHECK(hipEventRecord(ev_[k], on)); };
+    auto sub_prev = now();
+    auto sublap = [&](int k) { if (prof) { auto t = now(); sub[k] += std::chrono::duration<double, std::micro>(t - sub_prev).count(); sub_prev = t; } };
     auto emit = [&]() {
     bool tables_pending = true;
+    sublap(5);
     auto clear = [&](const FrameBuffers& b, const FrameConst& c) {
         if (tables_pending) launch_clear(b, c, gs, st.host_dev, tb, total);
         else launch_clear(b, c, gs);
@@ -1094,6 +1098,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         HIP_CHECK(hipStreamWaitEvent(gs, shade_done_[p], 0));
         if (timed || serialize_next_) HIP_CHECK(hipStreamWaitEvent(gs, shade_done_[p ^ 1u], 0));
     }
+    sublap(0);
     mark(7, gs);
     for (uint32_t k = 0; k < n_sets; ++k) {
         // a cascade no caster can reach stays cleared and out of the pass: its share of the launch-bound kernels (and a
@@ -1152,8 +1157,10 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     mark(4, gs);
     if (!frame_no_chain_) launch_raster(fb, fc, cap_, gs);
     mark(5, gs);
+    sublap(1);
     if (overlap_) HIP_CHECK(hipEventRecord(geo_done_[p], gs));
     if (overlap) HIP_CHECK(hipStreamWaitEvent(stream_, geo_done_[p], 0));
+    sublap(2);
     mark(8, stream_);       // shading starts here on its own stream (the hand-over from the geometry stream takes a few us)
     {
         uint64_t ran = 0;
@@ -1189,7 +1196,9 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         launch_overlay(op, op.tiles_x * ((surface_h_ + kTile - 1) / kTile), stream_);
     }
     mark(6, stream_);
+    sublap(3);
     if (overlap_) HIP_CHECK(hipEventRecord(shade_done_[p], stream_));
+    sublap(4);
     };
     emit();
     lap(3);
@@ -1206,7 +1215,10 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     if (prof && ++acc_n == 256) {
         std::fprintf(stderr, "rnd host us/frame: build+ensure %.1f, staging wait %.1f, stage+h2d %.1f, launches %.1f, d2h %.1f\n",
                      acc[0] / 256, acc[1] / 256, acc[2] / 256, acc[3] / 256, acc[4] / 256);
+        std::fprintf(stderr, "  launches: stream waits %.1f, geometry launches %.1f, hand-over events %.1f, shading launch %.1f, shade_done record %.1f\n",
+                     sub[0] / 256, sub[1] / 256, sub[2] / 256, sub[3] / 256, sub[4] / 256);
         for (double& a : acc) a = 0; acc_n = 0;
+        for (double& a : sub) a = 0;
     }
     frame_pending_ = true;
     stats_ = rnd_frame_stats{};
