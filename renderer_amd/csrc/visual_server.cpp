@@ -103,8 +103,11 @@ VisualServer::VisualServer(uint32_t width, uint32_t height, int device) : device
     for (int k = 0; k < 2; ++k) {
         HIP_CHECK(hipEventCreateWithFlags(&geo_done_[k], hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&shade_done_[k], hipEventDisableTiming));
+        if (k == 0) HIP_CHECK(hipEventCreateWithFlags(&switch_ev_, hipEventDisableTiming));
     }
     if (const char* e = std::getenv("RND_OVERLAP")) overlap_ = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RND_TUNE")) tune_enabled_ = std::atoi(e) != 0;
+    for (hipEvent_t& e : tune_ev_) HIP_CHECK(hipEventCreate(&e));
     if (const char* e = std::getenv("RND_NO_CHAIN")) allow_no_chain_ = std::atoi(e) != 0;
     // SceneUniform defaults — visual_server.rs:63-68
     projection_ = perspective_lh(1.3f, 1.667f, 0.05f, 100.0f);
@@ -165,9 +168,11 @@ VisualServer::~VisualServer() {
         for (auto& e : es.ev) if (e) (void)hipEventDestroy(e);
     if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
     if (geo_stream_) (void)hipStreamDestroy(geo_stream_);
+    for (hipEvent_t e : tune_ev_) if (e) (void)hipEventDestroy(e);
     for (int k = 0; k < 2; ++k) {
         if (geo_done_[k]) (void)hipEventDestroy(geo_done_[k]);
         if (shade_done_[k]) (void)hipEventDestroy(shade_done_[k]);
+        if (k == 0 && switch_ev_) (void)hipEventDestroy(switch_ev_);
     }
 }
 
@@ -184,6 +189,7 @@ void VisualServer::apply_size(uint32_t sw, uint32_t sh, float f) {
     if (f != 1.0f && world_ > 1) throw Error(RND_ERR_UNSUPPORTED, "render_size_factor != 1 on a tile partition is not built");
     finish();
     chain_free_streak_ = 0;          // (a changed scene or target: the record chain again until frames show they do not need it)
+    tune_reset();
     surface_w_ = sw; surface_h_ = sh; width_ = w; height_ = h; render_size_factor_ = f;
     ext_tiles_ = nullptr; ext_tiles_bytes_ = 0; ext_packed_ = nullptr;
     have_frame_ = false;
@@ -197,6 +203,7 @@ void VisualServer::set_msaa(uint32_t n) {
     if (n == msaa_) return;
     finish();
     chain_free_streak_ = 0;          // (a changed scene or target: the record chain again until frames show they do not need it)
+    tune_reset();
     msaa_ = n;
     have_frame_ = false;
     rebuild_tiles();    // recreate_render_targets (visual_server.rs:178-181): one visibility plane per sample
@@ -244,6 +251,7 @@ void VisualServer::set_tile_partition(uint32_t rank, uint32_t world) {
     if (world > 1 && scaled()) throw Error(RND_ERR_UNSUPPORTED, "render_size_factor != 1 on a tile partition is not built");
     finish();
     chain_free_streak_ = 0;          // (a changed scene or target: the record chain again until frames show they do not need it)
+    tune_reset();
     rank_ = rank; world_ = world;
     ext_tiles_ = nullptr; ext_tiles_bytes_ = 0;
     have_frame_ = false;
@@ -269,6 +277,7 @@ void VisualServer::register_mesh(uint32_t mesh_id, uint32_t n_submeshes, const r
     use_device();
     finish();
     chain_free_streak_ = 0;          // (a changed scene or target: the record chain again until frames show they do not need it)
+    tune_reset();
     auto old = meshes_.find(mesh_id);
     if (old != meshes_.end()) {
         for (auto& s : old->second.submeshes) { s.vertex_buffer.release(); s.positions.release(); s.index_buffer.release(); s.chunks.release(); }
@@ -419,6 +428,7 @@ void VisualServer::reset_scene() {
     use_device();
     finish();
     chain_free_streak_ = 0;          // (a changed scene or target: the record chain again until frames show they do not need it)
+    tune_reset();
     for (auto it = meshes_.begin(); it != meshes_.end();) {
         if (it->first == kQuadMeshId) { ++it; continue; }
         for (auto& s : it->second.submeshes) { s.vertex_buffer.release(); s.positions.release(); s.index_buffer.release(); s.chunks.release(); }
@@ -730,6 +740,63 @@ struct ScratchArena {
     }
 };
 
+// This frame's launch mode: true = geometry on the internal stream beside the previous frame's shading, false =
+// everything on the context's stream.  Frames with 60 us of shading or more overlap (measured: C3 +6 %, C4 +4 %).  Below
+// that the hand-over between the streams (two cross-queue dependencies per frame) can cost more than the overlap gains,
+// and which way it goes does not follow from the shading time (C2, 27 us: 13 760 frames/s overlapped, 12 950 serial; the
+// share of one rank of eight of C3, 26 us: 12 700 / 14 060; C1', 19 us: 6650 / 7030), so both are measured: kTuneWindow
+// frames each after kTuneSettle frames to settle, between two events on the context's stream, no synchronization (the
+// result is looked at when the last event has completed).  A timed frame or a finish() inside a window voids it.
+bool VisualServer::tune_overlap(bool timed) {
+    const bool guess = !(have_timings_ && timings_.shade_ms < 0.03f);
+    if (!tune_enabled_ || !overlap_) return guess;
+    if (have_timings_ && timings_.shade_ms >= 0.06f) { tune_reset(); return true; }
+    const bool fallback = tune_decided_ ? tune_choice_ : guess;
+    if (timed) {
+        if (tune_state_ == kTuneProbeOverlap || tune_state_ == kTuneProbeSerial) tune_state_ = kTuneIdle;
+        tune_mark_ = -1;
+        return fallback;
+    }
+    switch (tune_state_) {
+    case kTuneIdle:
+        tune_state_ = kTuneProbeOverlap; tune_i_ = 0;
+        [[fallthrough]];
+    case kTuneProbeOverlap:
+    case kTuneProbeSerial: {
+        const bool mode = tune_state_ == kTuneProbeOverlap;
+        const int base = mode ? 0 : 2;
+        if (tune_i_ == kTuneSettle) tune_mark_ = base;
+        if (tune_i_ == kTuneSettle + kTuneWindow) {
+            tune_mark_ = base + 1;
+            tune_state_ = mode ? kTuneProbeSerial : kTuneWait;
+            tune_i_ = 0;
+        } else {
+            ++tune_i_;
+        }
+        return mode;
+    }
+    case kTuneWait:
+        if (hipEventQuery(tune_ev_[3]) == hipSuccess) {
+            if (hipEventElapsedTime(&tune_ms_[0], tune_ev_[0], tune_ev_[1]) == hipSuccess &&
+                hipEventElapsedTime(&tune_ms_[1], tune_ev_[2], tune_ev_[3]) == hipSuccess) {
+                // (the mode in use stays unless the other one is 2 % faster)
+                const bool was = tune_decided_ ? tune_choice_ : guess;
+                tune_choice_ = was ? !(tune_ms_[1] < 0.98f * tune_ms_[0]) : (tune_ms_[0] < 0.98f * tune_ms_[1]);
+                tune_decided_ = true;
+                static const bool dbg = std::getenv("RND_TUNE_DEBUG") != nullptr;
+                if (dbg) std::fprintf(stderr, "rnd tune: %u frames overlapped %.3f ms, serial %.3f ms -> %s\n", kTuneWindow, tune_ms_[0], tune_ms_[1], tune_choice_ ? "overlap" : "serial");
+            }
+            tune_state_ = kTuneHolding; tune_i_ = 0;
+        }
+        (void)hipGetLastError();        // (hipErrorNotReady is not an error here)
+        return fallback;
+    case kTuneHolding:
+        if (++tune_i_ >= kTuneHold) tune_state_ = kTuneIdle;
+        return fallback;
+    }
+    return fallback;
+}
+
 void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t noalloc_bytes) {
     const bool noalloc = noalloc_out != nullptr;
     static const bool prof = std::getenv("RND_HOST_PROFILE") != nullptr;
@@ -746,7 +813,8 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     // Overlap pays when there is shading to hide the geometry chain behind: the hand-over between the two
     // streams costs ~25 us per frame (measured: C3 +6 %, C4 +4 %, C2 +2 %; C1', 20 us of shading, -8 %),
     // so frames whose last measured shading time is below 30 us stay on one stream.
-    const bool overlap = overlap_ && !noalloc && !(have_timings_ && timings_.shade_ms < 0.03f);
+    const bool timed_frame = force_timed_ > 0 || frame_counter_ < 4 || frame_counter_ % kTimingStride == 0;
+    const bool overlap = overlap_ && !noalloc && tune_overlap(timed_frame);
     hipStream_t const gs = overlap ? geo_stream_ : stream_;      // the geometry phase's stream
     std::vector<DrawItem>& items = items_;
     std::vector<uint32_t>&vert_bases = vert_bases_, &tri_bases = tri_bases_, &unit_bases = unit_bases_;
@@ -1063,7 +1131,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
 
     // per-kernel timing events on a sample of the frames (every kTimingStride-th, and the first few):
     // eight event records per frame are a noticeable share of the host's enqueue time
-    const bool timed = force_timed_ > 0 || frame_counter_ < 4 || frame_counter_ % kTimingStride == 0;
+    const bool timed = timed_frame;
     if (force_timed_) --force_timed_;
     ++frame_counter_;
     hipEvent_t* ev_ = nullptr;
@@ -1090,7 +1158,13 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     // shadow cascades: depth-only passes of the same pipeline (cull, transform, setup, bins, raster)
     // into kShadowSize^2 visibility buffers, one per (directional light, cascade)
     // the buffers only the geometry phase uses exist once: geometry phases follow each other
-    if (last_geo_stream_ && last_geo_stream_ != gs) HIP_CHECK(hipStreamWaitEvent(gs, geo_done_[p ^ 1u], 0));
+    // (a frame whose geometry runs on another stream than the previous frame's — the launch mode changed — waits for
+    // everything that stream holds: one event recorded then, so that frames of the one-stream mode record none at all;
+    // two event records a frame cost C1' 5 % of its frame rate)
+    if (last_geo_stream_ && last_geo_stream_ != gs) {
+        HIP_CHECK(hipEventRecord(switch_ev_, last_geo_stream_));
+        HIP_CHECK(hipStreamWaitEvent(gs, switch_ev_, 0));
+    }
     last_geo_stream_ = gs;
     if (overlap) {
         // this parity's buffers (shadow layers included) were last read by the shading of the frame before
@@ -1158,7 +1232,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     if (!frame_no_chain_) launch_raster(fb, fc, cap_, gs);
     mark(5, gs);
     sublap(1);
-    if (overlap_) HIP_CHECK(hipEventRecord(geo_done_[p], gs));
+    if (overlap) HIP_CHECK(hipEventRecord(geo_done_[p], gs));
     if (overlap) HIP_CHECK(hipStreamWaitEvent(stream_, geo_done_[p], 0));
     sublap(2);
     mark(8, stream_);       // shading starts here on its own stream (the hand-over from the geometry stream takes a few us)
@@ -1197,7 +1271,8 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     }
     mark(6, stream_);
     sublap(3);
-    if (overlap_) HIP_CHECK(hipEventRecord(shade_done_[p], stream_));
+    if (overlap) HIP_CHECK(hipEventRecord(shade_done_[p], stream_));
+    if (tune_mark_ >= 0) { HIP_CHECK(hipEventRecord(tune_ev_[tune_mark_], stream_)); tune_mark_ = -1; }
     sublap(4);
     };
     emit();
@@ -1286,6 +1361,7 @@ void VisualServer::render_noalloc(void* out_dev, uint64_t out_bytes) {
 }
 
 void VisualServer::finish() {
+    if (tune_state_ == kTuneProbeOverlap || tune_state_ == kTuneProbeSerial) { tune_state_ = kTuneIdle; tune_mark_ = -1; }
     if (!frame_pending_) return;
     use_device();
     uint32_t grew = 0;
@@ -1537,6 +1613,8 @@ void VisualServer::set_stream(hipStream_t s) {
     use_device();
     finish();
     HIP_CHECK(hipStreamSynchronize(stream_));
+    if (geo_stream_) HIP_CHECK(hipStreamSynchronize(geo_stream_));
+    last_geo_stream_ = nullptr;          // (nothing is in flight: the next frame has nothing to wait for)
     if (own_stream_ && stream_) HIP_CHECK(hipStreamDestroy(stream_));
     if (s) { stream_ = s; own_stream_ = false; }
     else { HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking)); own_stream_ = true; }

@@ -245,8 +245,22 @@ private:
     // (index = frame parity): per-frame tables, clip positions (frames that keep them), visibility buffer, counters.
     hipStream_t geo_stream_ = nullptr;
     hipEvent_t geo_done_[2] = {}, shade_done_[2] = {};
+    hipEvent_t switch_ev_ = nullptr;     // recorded on the previous frame's geometry stream when the launch mode changes
     uint32_t parity_ = 0;              // buffers of the last enqueued frame
     bool overlap_ = true;              // RND_OVERLAP=0: everything on stream_
+    // Which of the two launch modes is faster for small frames (shading below 60 us) is measured, not guessed: a window of
+    // frames in each mode between two events on the context's stream, the better one kept for kTuneHold frames
+    // (tune_overlap in visual_server.cpp; RND_TUNE=0 leaves the fixed rule of round 2: overlap unless shading < 30 us).
+    enum TuneState { kTuneIdle, kTuneProbeOverlap, kTuneProbeSerial, kTuneWait, kTuneHolding };
+    static constexpr uint32_t kTuneSettle = 8, kTuneWindow = 24, kTuneHold = 4096;
+    bool tune_enabled_ = true, tune_decided_ = false, tune_choice_ = true;
+    TuneState tune_state_ = kTuneIdle;
+    uint32_t tune_i_ = 0;
+    int tune_mark_ = -1;               // the event to record after this frame's shading, or -1
+    hipEvent_t tune_ev_[4] = {};
+    float tune_ms_[2] = {0.0f, 0.0f};  // last measured window: overlapped, serial
+    bool tune_overlap(bool timed);
+    void tune_reset() { tune_state_ = kTuneIdle; tune_decided_ = false; tune_mark_ = -1; }
     hipStream_t last_geo_stream_ = nullptr;   // where the previous frame's geometry ran (the two modes can alternate)
     bool have_timings_ = false;        // timings_ holds a measured frame
     bool serialize_next_ = false;      // the previous frame recorded timing events: keep this one's geometry off its shading
