@@ -245,6 +245,21 @@ private:
     // (index = frame parity): per-frame tables, clip positions (frames that keep them), visibility buffer, counters.
     hipStream_t geo_stream_ = nullptr;
     hipEvent_t geo_done_[2] = {}, shade_done_[2] = {};
+    // The shadow passes of a frame and its main pass's geometry meet only in the shading kernel: with a second set of
+    // the geometry-only buffers the shadow passes run on a stream of their own beside the main pass (RND_SHADOW_STREAM=0:
+    // one after the other on the geometry stream, as in rounds 1 and 2; frames with timing events always do that).
+    struct GeoSet {
+        DeviceBuffer<SnapVert> snap; DeviceBuffer<SetupRecord> records;
+        DeviceBuffer<uint32_t> tilewords, clip_queue, chunk_count, vblock_needed, active_units, tile_count, tile_offset, tile_cursor, entries, wide_list, tile_slices;
+        DeviceBuffer<uint2> raster_extra;
+        void release() {
+            snap.release(); records.release(); tilewords.release(); clip_queue.release(); chunk_count.release(); vblock_needed.release(); active_units.release();
+            tile_count.release(); tile_offset.release(); tile_cursor.release(); entries.release(); wide_list.release(); tile_slices.release(); raster_extra.release();
+        }
+    } shadow_geo_;
+    hipStream_t shadow_stream_ = nullptr;
+    hipEvent_t tables_ready_ = nullptr, shadows_done_ = nullptr;
+    bool shadow_concurrent_ = true;
     hipEvent_t switch_ev_ = nullptr;     // recorded on the previous frame's geometry stream when the launch mode changes
     uint32_t parity_ = 0;              // buffers of the last enqueued frame
     bool overlap_ = true;              // RND_OVERLAP=0: everything on stream_
