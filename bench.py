@@ -30,8 +30,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
 N_SIMDS, VALU_CLOCK_HZ = 256 * 4, 2.4e9      # a wave64 VALU instruction takes a SIMD's 32 lanes for 2 cycles (MI355X_MICROARCH.md)
-TIMED_FRAMES = 16          # frames with events around every kernel, after the throughput loop (outside `elapsed`)
-SETTLE_FRAMES = 200        # untimed frames before them when the run was short: the VALU-bound kernels take ~200 frames
+TIMED_FRAMES = 16          # frames with events around every kernel, before the warm-up and the timed steps (outside `elapsed`)
+SETTLE_FRAMES = 200        # untimed frames before them: the VALU-bound kernels take ~200 frames
                            # (60 ms) of load to reach the duration they keep (k_shade at C3: 0.179 ms after 25 frames,
                            # 0.167 after 65, 0.163 after 205 and after 805; the bandwidth-bound k_transform does not
                            # move), and the per-kernel table and the roofline entries describe the kernels, not the
@@ -295,23 +295,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    vs.mean_timings(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    # per-kernel durations: TIMED_FRAMES more frames of the same workload, each with HIP events around every
-    # kernel (on the streams the kernels are launched on) and without the overlap with its neighbours
-    settle = max(0, SETTLE_FRAMES - args.warmup - args.steps)
+    # Per-kernel durations first, outside `elapsed`: SETTLE_FRAMES untimed frames, then TIMED_FRAMES frames of the same
+    # workload with HIP events around every kernel (on the streams the kernels are launched on; a timed frame is not
+    # overlapped with its neighbours).  They come BEFORE the warm-up and the timed steps since round 3: the VALU-bound
+    # kernels follow the GPU's clock ramp (k_shade 0.179 ms after 25 frames of load, 0.163 after 205), and a run of
+    # `--warmup 5 --steps 20` straight from an idle GPU measured that ramp (3110 frames/s at C3 against 3550 in steady
+    # state) rather than the path.  The line says how many frames ran before the warm-up (`frames_before_warmup`).
+    settle = SETTLE_FRAMES
     for _ in range(settle):
         step()
     fence()
@@ -321,6 +311,19 @@ def main():
         step()
     fence()
     mean, worst, n_frames = vs.timing_stats()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
     stats = vs.frame_stats()
     frame_check = None
     if world > 1:
@@ -400,7 +403,7 @@ def main():
             "kernels": kernels,
             "dropped_frames": driver.dropped,
             "frame_check": frame_check,
-            "gpu_frame_ms": round(mean["frame_ms"], 4), "timed_frames": n_frames, "settle_frames_before_kernel_timing": settle,
+            "gpu_frame_ms": round(mean["frame_ms"], 4), "timed_frames": n_frames, "frames_before_warmup": settle + TIMED_FRAMES,
             "frame_stats": stats,
         }
         if world == 1 and not args.no_cpu_baseline:
