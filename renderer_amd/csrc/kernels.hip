@@ -226,6 +226,8 @@ __global__ __launch_bounds__(256) void k_cull(FrameBuffers fb) {
     const uint32_t lane = lane_id();
     bool active = false;
     uint32_t it = 0, chunk = 0, vb0 = 0, vb1 = 0;
+    uint4 bounds = make_uint4(0u, 0u, 0u, 0u);
+    const bool want_bounds = fb.early_z != 0u && fb.setup_pass != 0u && fb.unit_bounds != nullptr;
     // (unit, view): the views of a multi-view pass are culled one by one against their own volume
     const uint32_t per_view = max(fc.n_units_view, 1u);
     const uint32_t view = gu / per_view, u = gu - view * per_view;
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(256) void k_cull(FrameBuffers fb) {
                 active = true;      // positions do not go through projection * view
             } else {
                 bool out_l = true, out_r = true, out_b = true, out_t = true, out_n = true, out_f = true, w_pos = true;
-                float y_lo = 3.0e38f, y_hi = -3.0e38f;
+                float y_lo = 3.0e38f, y_hi = -3.0e38f, x_lo = 3.0e38f, x_hi = -3.0e38f, z_lo = 3.0e38f;
                 for (uint32_t c = 0; c < 8; ++c) {
                     const float4 p = clip_position(d, view_pv(fc, view), (c & 1u) ? ci.hi[0] : ci.lo[0], (c & 2u) ? ci.hi[1] : ci.lo[1],
                                                    (c & 4u) ? ci.hi[2] : ci.lo[2]);
@@ -257,8 +259,22 @@ __global__ __launch_bounds__(256) void k_cull(FrameBuffers fb) {
                     w_pos = w_pos && finite && p.w > e;
                     const float yn = p.y / p.w;
                     y_lo = fminf(y_lo, yn); y_hi = fmaxf(y_hi, yn);
+                    if (want_bounds) { const float xn = p.x / p.w; x_lo = fminf(x_lo, xn); x_hi = fmaxf(x_hi, xn); z_lo = fminf(z_lo, p.z / p.w); }
                 }
                 active = !(out_l || out_r || out_b || out_t || out_n || out_f);
+                if (active && w_pos && want_bounds) {
+                    // Every vertex of the chunk lies in its box; with all eight corners in front of the eye the box's image is
+                    // the convex hull of the corners' images, so the corners bound the chunk's pixels (two pixels of slack for
+                    // snapping and rounding, as below) and its depth (z/w takes its extremes at corners; 1e-4 of slack: the
+                    // corners do not go through K1's arithmetic).  k_setup's second early-depth pass drops the whole unit when
+                    // every 8x8 block of the rect already holds something nearer everywhere.
+                    const float half_w = 0.5f * (float)fc.width, half_h = 0.5f * (float)fc.view_h;
+                    const float sx0 = fmaxf((x_lo + 1.0f) * half_w - 2.0f, 0.0f), sx1 = fminf((x_hi + 1.0f) * half_w + 2.0f, (float)fc.width - 1.0f);
+                    const float sy0 = fmaxf((1.0f - y_hi) * half_h - 2.0f, 0.0f), sy1 = fminf((1.0f - y_lo) * half_h + 2.0f, (float)fc.view_h - 1.0f);
+                    if (sx0 <= sx1 && sy0 <= sy1)
+                        bounds = make_uint4(((uint32_t)sx0 >> 3) | (((uint32_t)sy0 >> 3) << 16), ((uint32_t)sx1 >> 3) | (((uint32_t)sy1 >> 3) << 16),
+                                            __float_as_uint(z_lo - 1.0e-4f), 1u);
+                }
                 if (active && w_pos && fc.world > 1) {
                     // rows the box can reach, two pixels of slack for snapping and rounding
                     const float half_h = 0.5f * (float)fc.height;
@@ -283,7 +299,9 @@ __global__ __launch_bounds__(256) void k_cull(FrameBuffers fb) {
         if (lane == (uint32_t)leader) base = atomicAdd(&fb.counters->n_active, (uint32_t)__popcll(am));
         base = __shfl(base, leader);
         if (active) {
-            fb.active_units[base + (uint32_t)__popcll(am & ((1ull << lane) - 1ull))] = make_uint2(it, chunk | (view << kUnitViewShift));
+            const uint32_t slot = base + (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
+            fb.active_units[slot] = make_uint2(it, chunk | (view << kUnitViewShift));
+            if (want_bounds) fb.unit_bounds[slot] = bounds;
             if (vb1 - vb0 >= 64u) fb.counters->all_verts = 1u;
             // (the flag names a draw item that has vertices in the block: k_transform starts from it instead of searching)
             else for (uint32_t b = vb0; b <= vb1 && b < n_vblocks; ++b) fb.vblock_needed[view * n_vblocks + b] = it + 1u;
@@ -601,6 +619,7 @@ struct GlobalSinkT {
     unsigned long long* vis;
     uint32_t tiles_x, rank, world;
     uint32_t plane_stride;              // words between the planes of consecutive MSAA samples
+    uint32_t test;                      // kEarlyZ: compare before the atomic (uniform; off in the first of two passes, whose surfaces hide nothing of each other: the load was a dependent round trip per raster round for nothing)
     __device__ __forceinline__ void operator()(int32_t i, int32_t j, float z, uint32_t id, uint32_t smp = 0) const {
         z = fminf(fmaxf(z, 0.0f), 1.0f);
         const uint32_t tx = (uint32_t)i / kTile, ty = (uint32_t)j / kTile;
@@ -611,7 +630,7 @@ struct GlobalSinkT {
             const uint32_t at = smp * plane_stride + (ty * tiles_x + tx) * kTilePixels + (((uint32_t)j % kTile) * kTile + ((uint32_t)i % kTile));
             unsigned long long* const word = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(vis) + (at << 3));
             if constexpr (kEarlyZ) {
-                if (!(key < __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return;
+                if (test && !(key < __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return;
             }
             __hip_atomic_fetch_min(word, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -893,13 +912,43 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
     const uint32_t first_t = chunk_s * chunk_tris;                         // first triangle of the chunk within its item
     const uint32_t item_tris = d->n_tris;
     const uint32_t n_here = item_tris > first_t ? min(item_tris - first_t, chunk_tris) : 0u;
+    if constexpr (kEarlyZ) {
+        if (setup_pass == 2u && fb.unit_bounds) {
+            // the whole unit behind what pass 1 drew?  (k_cull's bounds of the unit against k_hiz's farthest depths)
+            const uint4 ub = fb.unit_bounds[unit_index];
+            const uint32_t bx0 = ub.x & 0xFFFFu, by0 = ub.x >> 16, bw = (ub.y & 0xFFFFu) - bx0 + 1u, bh = (ub.y >> 16) - by0 + 1u;
+            const uint32_t n_b = bw * bh;
+            if (ub.w != 0u && n_b <= 16384u) {
+                const float z_near_unit = __uint_as_float(ub.z);
+                const float inv_bw = __builtin_amdgcn_rcpf((float)bw);
+                bool open = false;
+                for (uint32_t k = threadIdx.x; k < n_b; k += 256u) {
+                    uint32_t dy = (uint32_t)(((float)k + 0.5f) * inv_bw);
+                    dy = dy * bw > k ? dy - 1u : ((dy + 1u) * bw <= k ? dy + 1u : dy);        // (exact k / bw from the estimate)
+                    const uint32_t bx = bx0 + (k - dy * bw), by = by0 + dy;
+                    const float farthest = fb.hiz[((by >> 2) * fc.tiles_x + (bx >> 2)) * 16u + ((by & 3u) * 4u + (bx & 3u))];
+                    open = open || !(z_near_unit > farthest);
+                }
+                if (!__syncthreads_or(open ? 1 : 0)) {
+                    if (threadIdx.x == 0) {
+                        fb.chunk_count[unit_index] = 0u;
+                        // (the host's measure of depth complexity keeps counting what was turned away, at the rate of the last
+                        // plain frame, or the variant would switch itself off)
+                        const unsigned long long f = ((unsigned long long)n_here * fb.bbox_px_hint_x16) >> 4;
+                        atomicAdd(&fb.stat_stripes[(unit_index % kStatStripes) * kStatStride], f << 32);
+                    }
+                    return;
+                }
+            }
+        }
+    }
     const uint32_t vb = d->vert_base, nv = d->n_verts, tri_base = d->tri_base;
     const bool alpha_item = (d->flags & kItemAlphaTest) != 0u;       // fragments take the texture alpha test
     gptr_u32 indices = (gptr_u32)d->indices;
     const bool tables_ok = guard(vb + nv <= fc.n_verts, fb.counters, kGuardSetup);
     const uint32_t chunk_base = unit_index * chunk_tris;
     const uint32_t n_tiles = fc.tiles_x * fc.tiles_y;
-    const GlobalSinkT<kEarlyZ> direct_sink{reinterpret_cast<unsigned long long*>(fb.vis), fc.tiles_x, fc.rank, fc.world, (uint32_t)fb.vis_stride};
+    const GlobalSinkT<kEarlyZ> direct_sink{reinterpret_cast<unsigned long long*>(fb.vis), fc.tiles_x, fc.rank, fc.world, (uint32_t)fb.vis_stride, setup_pass != 1u ? 1u : 0u};
     uint32_t valid = 0, frags = 0;      // (frags: per lane, summed at the end)
     // (a unit without triangles or with tables that do not fit runs no iteration; the loads below need nv >= 1)
     const uint32_t n_iters = (tables_ok && nv != 0u) ? (n_here + 255u) / 256u : 0u;

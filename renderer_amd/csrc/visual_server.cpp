@@ -154,7 +154,7 @@ VisualServer::~VisualServer() {
     for (auto& kv : meshes_)
         for (auto& s : kv.second.submeshes) { s.vertex_buffer.release(); s.positions.release(); s.index_buffer.release(); s.chunks.release(); }
     for (int k = 0; k < 2; ++k) { d_tables_[k].release(); d_clip_[k].release(); d_vis_[k].release(); d_counters_[k].release(); d_stat_stripes_[k].release(); }
-    d_snap_.release(); d_hiz_.release(); d_wide_list_.release(); d_tile_slices_.release(); d_raster_extra_.release();
+    d_snap_.release(); d_hiz_.release(); d_unit_bounds_.release(); d_wide_list_.release(); d_tile_slices_.release(); d_raster_extra_.release();
     d_records_.release(); d_tilewords_.release(); d_clip_queue_.release(); d_chunk_count_.release(); d_vblock_needed_.release(); d_active_units_.release(); d_tile_count_.release();
     d_tile_offset_.release(); d_tile_cursor_.release(); d_entries_.release();
     for (auto& kv : textures_) kv.second.texels.release();
@@ -876,6 +876,11 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     const uint32_t n_views_max = n_sets ? kShadowCascades : 1u;        // views of the frame's widest pass (buffer sizes)
     static_assert(kShadowCascades <= kMaxViews && kShadowCascades * kShadowSize <= kMaxRenderSize, "the cascades must stack into one render target");
     const bool overlay = fullscreen_ != 0 || !uiboxes_.empty() || !glyphs_.empty();
+    // Shadow passes on their own stream beside the main pass's geometry (second buffer set, below)?  Measured: C1' 720p
+    // 6990 -> 9560 frames/s, at 4K 5490 -> 7520, C2 + sun 5300 -> 5850: chains of small launches run side by side; C3 +
+    // sun + texture, 0.27 ms of shadow pass: 1505 -> 1476, two heavy passes only share the machine — so only while the last
+    // measured shadow pass took less than 0.2 ms.
+    const bool shadows_beside_frame = shadow_concurrent_ && n_sets != 0 && !noalloc && !(have_timings_ && timings_.shadow_ms >= 0.2f);
     if (noalloc && n_sets) throw Error(RND_ERR_UNSUPPORTED, "rnd_render_noalloc: directional lights need shadow cascades beyond the scratch array");
     static_assert(kPinnedCounterSets >= 1, "a frame without shadow passes has one counter set, pinned at creation");
     std::vector<ShadowSet> sets(n_sets);
@@ -921,7 +926,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     struct {
         float4* clip; SnapVert* snap; SetupRecord* records; uint32_t *tilewords, *clip_queue, *chunk_count, *active_units, *vblock_needed, *entries,
             *wide_list, *tile_slices, *tile_count, *tile_offset, *tile_cursor;
-        uint2* raster_extra; FrameCounters* counters; uint64_t* vis; float* hiz; unsigned long long* stripes;
+        uint2* raster_extra; FrameCounters* counters; uint64_t* vis; float* hiz; unsigned long long* stripes; uint4* unit_bounds;
     } bp{};
     const size_t n_vblocks = ((size_t)fc.n_verts / kVertexBlock + 2) * n_views_max;
     const size_t n_unit_words = std::max<size_t>(2 * (size_t)fc.n_units * n_views_max, 2);
@@ -954,6 +959,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         bp.stripes = arena.take<unsigned long long>((size_t)n_counter_sets * kStatStripes * kStatStride);
         bp.vis = arena.take<uint64_t>(n_tiles * kTilePixels * msaa_);
         bp.hiz = early_z_frame_ ? arena.take<float>(n_tiles * 16) : nullptr;
+        bp.unit_bounds = early_z_frame_ ? arena.take<uint4>(std::max<size_t>(fc.n_units, 1)) : nullptr;
     } else {
         if (store_clip && store_clip_fits) d_clip_[p].ensure(std::max<size_t>(fc.n_verts, 1));        // (the main pass's only: shading reads it)
         d_snap_.ensure(n_view_verts);
@@ -966,7 +972,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         d_wide_list_.ensure(cap_.wide_list);
         d_tile_slices_.ensure(std::max<size_t>(n_tiles, n_sets ? (size_t)kShadowCascades * kShadowTiles : 0));
         d_raster_extra_.ensure(kRasterExtraCap);
-        if (n_sets && shadow_concurrent_) {
+        if (shadows_beside_frame) {
             GeoSet& g = shadow_geo_;
             g.snap.ensure(n_view_verts); g.records.ensure(cap_.records); g.tilewords.ensure(2 * (size_t)cap_.records);
             g.clip_queue.ensure(2 * (size_t)cap_.clip_queue); g.chunk_count.ensure(n_count_words); g.active_units.ensure(n_unit_words);
@@ -985,8 +991,9 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         bp.counters = d_counters_[p].ptr; bp.vis = d_vis_[p].ptr;
         d_stat_stripes_[p].ensure((size_t)n_counter_sets * kStatStripes * kStatStride);
         bp.stripes = reinterpret_cast<unsigned long long*>(d_stat_stripes_[p].ptr);
-        if (early_z_frame_) d_hiz_.ensure(n_tiles * 16);
+        if (early_z_frame_) { d_hiz_.ensure(n_tiles * 16); d_unit_bounds_.ensure(std::max<size_t>(fc.n_units, 1)); }
         bp.hiz = d_hiz_.ptr;
+        bp.unit_bounds = early_z_frame_ ? d_unit_bounds_.ptr : nullptr;
     }
 
     // stage the per-frame tables in pinned memory and upload them
@@ -1117,6 +1124,8 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     fb.split_units = split_units_;
     fb.setup_pass = early_z_frame_ && split_units_ != 0u && split_units_ < fc.n_units ? 1u : 0u;
     fb.hiz = bp.hiz;
+    fb.bbox_px_hint_x16 = bbox_px_hint_x16_;
+    fb.unit_bounds = bp.unit_bounds;
     fb.launch_order = d_launch_order_.ptr; fb.n_owned = n_owned_;
     fb.dims = ShadeDims{fc.n_lights, fc.n_items, fc.width, fc.height, fc.tiles_x,
                         fc.tiles_x > 1u ? (uint32_t)((1ull << 32) / fc.tiles_x) + 1u : 0u, fc.rank, fc.world};
@@ -1174,10 +1183,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         tables_pending = false;
     };
     // shadow passes beside the main pass's geometry (their own stream and buffer set) unless the frame is timed
-    // (measured: C1' 720p 6990 -> 9560 frames/s, at 4K 5490 -> 7520, C2 + sun 5300 -> 5850: chains of small launches run
-    // side by side; C3 + sun + texture, 0.27 ms of shadow pass: 1505 -> 1476, two heavy passes only share the machine — so
-    // only while the last measured shadow pass took less than 0.2 ms)
-    const bool shadows_beside = shadow_concurrent_ && n_sets != 0 && !timed && !noalloc && !(have_timings_ && timings_.shadow_ms >= 0.2f);
+    const bool shadows_beside = shadows_beside_frame && !timed;
     hipStream_t const ss = shadows_beside ? shadow_stream_ : gs;
     // shadow cascades: depth-only passes of the same pipeline (cull, transform, setup, bins, raster)
     // into kShadowSize^2 visibility buffers, one per (directional light, cascade)
@@ -1363,6 +1369,9 @@ void VisualServer::note_depth_complexity(uint64_t n_fragments) {
     // (n_fragments: pixel centres in the bboxes of the small triangles, about twice what they cover: C3 1.4 per pixel,
     // C4 — ten layers — 30)
     const double per_sample = (double)n_fragments / ((double)width_ * height_ * msaa_);
+    // (while the plain variant runs, the count is exact and gives the rate at which the early-depth variant's second pass
+    // counts the triangles of the units it turns away whole: bbox pixels per input triangle, x 16)
+    if (!early_z_state_ && fc_.n_tris) bbox_px_hint_x16_ = (uint32_t)std::min<uint64_t>(n_fragments * 16u / fc_.n_tris, 0xFFFFu);
     if (per_sample >= 6.0) early_z_state_ = true;
     else if (per_sample < 4.0) early_z_state_ = false;
 }
