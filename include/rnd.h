@@ -94,13 +94,13 @@ typedef struct rnd_frame_stats {
     uint64_t n_setup;         /* Nt_vis: setup records written (after cull/clip) */
     uint64_t n_bin_entries;   /* Nbin: (record, tile) pairs */
     uint64_t n_pixels;        /* P: pixels this context rasterizes (owned tiles only) */
-    uint64_t n_fragments;     /* pixel centres in the bboxes of the small triangles rasterized at setup: / (P * samples) ~ twice the depth complexity */
+    uint64_t n_fragments;     /* pixel centres in the bboxes of the small triangles rasterized at setup (bboxes of up to 32 pixel centres; 64 in early-depth frames): / (P * samples) ~ twice the depth complexity */
     uint32_t n_draw_items;    /* M */
     uint32_t n_lights;        /* L */
     uint32_t n_tiles;         /* tiles owned by this context */
     uint32_t overflow;        /* 1 if an internal buffer had to grow and the frame was re-run */
     uint32_t early_depth;     /* 1 if the frame ran the setup variant that tests depth before the visibility atomic */
-    uint32_t reserved;
+    uint32_t n_units_hidden;   /* early-depth frames: work units (runs of 256 or 1024 triangles) turned away whole behind what the first pass drew */
 } rnd_frame_stats;
 
 /* ---- lifecycle -------------------------------------------------------------------- */

@@ -76,7 +76,7 @@ pub struct rnd_frame_stats {
     pub n_tiles: u32,
     pub overflow: u32,
     pub early_depth: u32,
-    pub reserved: u32,
+    pub n_units_hidden: u32,
 }
 
 extern "C" {

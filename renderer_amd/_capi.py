@@ -55,7 +55,7 @@ class FrameStats(C.Structure):
     _fields_ = [
         ("n_vertices", C.c_uint64), ("n_triangles", C.c_uint64), ("n_setup", C.c_uint64),
         ("n_bin_entries", C.c_uint64), ("n_pixels", C.c_uint64), ("n_fragments", C.c_uint64), ("n_draw_items", C.c_uint32),
-        ("n_lights", C.c_uint32), ("n_tiles", C.c_uint32), ("overflow", C.c_uint32), ("early_depth", C.c_uint32), ("reserved", C.c_uint32),
+        ("n_lights", C.c_uint32), ("n_tiles", C.c_uint32), ("overflow", C.c_uint32), ("early_depth", C.c_uint32), ("n_units_hidden", C.c_uint32),
     ]
 
     def as_dict(self):

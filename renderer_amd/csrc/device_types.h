@@ -220,7 +220,8 @@ struct FrameCounters {
     uint32_t n_extra;          // (tile, slice) work items of heavy tiles beyond their first raster workgroup
     uint32_t n_fragments;      // pixel centres in the bboxes of the triangles k_setup rasterizes itself (saturating; summed by k_scan_tiles, or by k_shade in a frame without the record chain)
     uint32_t chain_needed;     // k_setup wrote a record or queued a triangle for the clipper: the pass needs k_clip .. k_raster
-    uint32_t pad[1];
+    uint32_t n_far;            // early-depth frames, two passes: work units of the far items that passed k_cull (candidates of k_cull_far)
+    uint32_t n_near;           // ... and the number of active units of the first pass (k_hiz notes it; k_cull_far appends the far survivors behind them)
 };
 
 // What the frame's shading kernel reports to the host through mapped pinned memory, so that the host learns of an

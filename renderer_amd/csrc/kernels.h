@@ -59,7 +59,8 @@ struct FrameBuffers {
     uint32_t split_units;           // early_z, two passes: units numbered below this (the nearest draw items) form pass 1
     uint32_t bbox_px_hint_x16;      // early_z, two passes: bbox pixels per input triangle (x 16) of the last frame that ran the plain variant; a unit turned away whole counts its triangles at this rate in the depth-complexity measure
     float* hiz;                     // early_z, two passes: farthest depth per 8x8 pixel block, 16 per tile
-    uint4* unit_bounds;             // early_z, two passes: per active unit (k_cull -> k_setup pass 2) its rect of 8x8 blocks (x0 | y0 << 16, x1 | y1 << 16), the bits of a depth no sample of it is nearer than, and 1 (0: no bounds, no test)
+    uint2* far_units;               // early_z, two passes: (item, chunk) of the far items' units that passed k_cull (k_cull -> k_cull_far)
+    uint4* unit_bounds;             // ... and per such unit its rect of 8x8 blocks (x0 | y0 << 16, x1 | y1 << 16), the bits of a depth no sample of it is nearer than, and 1 (0: no bounds, no test)
     // the counter sets of all passes of the frame (shadow cascades, main pass, MSAA samples), read by the shading
     // kernel: a frame whose geometry overflowed an internal stream is not presented (the image keeps the previous
     // frame) and the host is told through `report`

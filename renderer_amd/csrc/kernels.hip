@@ -227,7 +227,10 @@ __global__ __launch_bounds__(256) void k_cull(FrameBuffers fb) {
     bool active = false;
     uint32_t it = 0, chunk = 0, vb0 = 0, vb1 = 0;
     uint4 bounds = make_uint4(0u, 0u, 0u, 0u);
-    const bool want_bounds = fb.early_z != 0u && fb.setup_pass != 0u && fb.unit_bounds != nullptr;
+    // early-depth frames in two passes: the units of the far items are only candidates here (with bounds); k_cull_far takes
+    // them up again when the near items are drawn
+    const bool want_bounds = fb.early_z != 0u && fb.setup_pass != 0u && fb.unit_bounds != nullptr && fb.far_units != nullptr;
+    bool far_item = false;
     // (unit, view): the views of a multi-view pass are culled one by one against their own volume
     const uint32_t per_view = max(fc.n_units_view, 1u);
     const uint32_t view = gu / per_view, u = gu - view * per_view;
@@ -238,6 +241,7 @@ __global__ __launch_bounds__(256) void k_cull(FrameBuffers fb) {
         it = fb.unit_bases[fc.n_items + 1u + find_item(fb.unit_bases, fc.n_items, u)];
         const DrawItem& d = fb.items[it];
         chunk = u - d.unit_base;
+        far_item = want_bounds && d.unit_base >= fb.split_units;
         const uint32_t flags = d.flags;
         if (!(flags & kItemSkip) && guard(chunk < d.n_chunks, fb.counters, kGuardSetup)) {
             const ChunkInfo ci = d.chunks[chunk];
@@ -262,18 +266,19 @@ __global__ __launch_bounds__(256) void k_cull(FrameBuffers fb) {
                     if (want_bounds) { const float xn = p.x / p.w; x_lo = fminf(x_lo, xn); x_hi = fmaxf(x_hi, xn); z_lo = fminf(z_lo, p.z / p.w); }
                 }
                 active = !(out_l || out_r || out_b || out_t || out_n || out_f);
-                if (active && w_pos && want_bounds) {
+                if (active && w_pos && far_item) {
                     // Every vertex of the chunk lies in its box; with all eight corners in front of the eye the box's image is
                     // the convex hull of the corners' images, so the corners bound the chunk's pixels (two pixels of slack for
-                    // snapping and rounding, as below) and its depth (z/w takes its extremes at corners; 1e-4 of slack: the
-                    // corners do not go through K1's arithmetic).  k_setup's second early-depth pass drops the whole unit when
+                    // snapping and rounding, as below) and its depth (z/w takes its extremes at corners; 4e-6 of slack, ten
+                    // times the rounding of K1's routine, which evaluates the corners here as it does the vertices there: the layers of C4 lie
+                    // 6e-5 apart in depth, a slack of 1e-4 turned none of them away).  k_setup's second early-depth pass drops the whole unit when
                     // every 8x8 block of the rect already holds something nearer everywhere.
                     const float half_w = 0.5f * (float)fc.width, half_h = 0.5f * (float)fc.view_h;
                     const float sx0 = fmaxf((x_lo + 1.0f) * half_w - 2.0f, 0.0f), sx1 = fminf((x_hi + 1.0f) * half_w + 2.0f, (float)fc.width - 1.0f);
                     const float sy0 = fmaxf((1.0f - y_hi) * half_h - 2.0f, 0.0f), sy1 = fminf((1.0f - y_lo) * half_h + 2.0f, (float)fc.view_h - 1.0f);
                     if (sx0 <= sx1 && sy0 <= sy1)
                         bounds = make_uint4(((uint32_t)sx0 >> 3) | (((uint32_t)sy0 >> 3) << 16), ((uint32_t)sx1 >> 3) | (((uint32_t)sy1 >> 3) << 16),
-                                            __float_as_uint(z_lo - 1.0e-4f), 1u);
+                                            __float_as_uint(z_lo - 4.0e-6f), 1u);
                 }
                 if (active && w_pos && fc.world > 1) {
                     // rows the box can reach, two pixels of slack for snapping and rounding
@@ -292,6 +297,19 @@ __global__ __launch_bounds__(256) void k_cull(FrameBuffers fb) {
             }
         }
     }
+    const unsigned long long fm = __ballot(active && far_item);
+    if (fm) {
+        const int leader = __ffsll((long long)fm) - 1;
+        uint32_t base = 0;
+        if (lane == (uint32_t)leader) base = atomicAdd(&fb.counters->n_far, (uint32_t)__popcll(fm));
+        base = __shfl(base, leader);
+        if (active && far_item) {
+            const uint32_t slot = base + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull));
+            fb.far_units[slot] = make_uint2(it, chunk);
+            fb.unit_bounds[slot] = bounds;
+        }
+        active = active && !far_item;
+    }
     const unsigned long long am = __ballot(active);
     if (am) {
         const int leader = __ffsll((long long)am) - 1;
@@ -299,9 +317,7 @@ __global__ __launch_bounds__(256) void k_cull(FrameBuffers fb) {
         if (lane == (uint32_t)leader) base = atomicAdd(&fb.counters->n_active, (uint32_t)__popcll(am));
         base = __shfl(base, leader);
         if (active) {
-            const uint32_t slot = base + (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
-            fb.active_units[slot] = make_uint2(it, chunk | (view << kUnitViewShift));
-            if (want_bounds) fb.unit_bounds[slot] = bounds;
+            fb.active_units[base + (uint32_t)__popcll(am & ((1ull << lane) - 1ull))] = make_uint2(it, chunk | (view << kUnitViewShift));
             if (vb1 - vb0 >= 64u) fb.counters->all_verts = 1u;
             // (the flag names a draw item that has vertices in the block: k_transform starts from it instead of searching)
             else for (uint32_t b = vb0; b <= vb1 && b < n_vblocks; ++b) fb.vblock_needed[view * n_vblocks + b] = it + 1u;
@@ -335,6 +351,7 @@ __global__ __launch_bounds__(256) void k_transform(const DrawItem* __restrict__ 
                                                    float4* __restrict__ clip, SnapVert* __restrict__ snap,
                                                    const uint32_t* __restrict__ vblock_needed,
                                                    const FrameCounters* __restrict__ counters) {
+    // (vblock_needed: this launch's row of flags — the far units' in the second launch of an early-depth frame)
     FrameConstRef fc = frame_const_ref(fcp);
     static_assert(kVertexBlock == 256, "one workgroup per vertex block");
     const uint32_t view = blockIdx.y;                                    // multi-view passes: one grid row per view
@@ -884,10 +901,17 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
     // Workgroups go to the eight XCDs round-robin (workgroup b to XCD b % 8), and each XCD has its own L2.  Units
     // next to each other in the list share vertices (the neighbouring rows of a mesh lie a few chunks apart), so
     // every XCD takes one contiguous eighth of the list instead of every eighth unit.
-    const uint32_t n_active = fb.counters->n_active;
-    const uint32_t per_xcd = (n_active + kXcds - 1u) / kXcds;
-    const uint32_t unit_index = (blockIdx.x % kXcds) * per_xcd + blockIdx.x / kXcds;
-    if (blockIdx.x / kXcds >= per_xcd || unit_index >= n_active) return;
+    // (early-depth frames in two passes: the first pass takes the units k_cull listed — the near items' —, the second those
+    // k_cull_far appended behind them)
+    const uint32_t setup_pass = kEarlyZ ? fb.setup_pass : 0u;
+    uint32_t range_lo = 0u, range_n = fb.counters->n_active;
+    if constexpr (kEarlyZ) {
+        if (setup_pass == 2u) { range_lo = min(fb.counters->n_near, range_n); range_n -= range_lo; }
+    }
+    const uint32_t per_xcd = (range_n + kXcds - 1u) / kXcds;
+    const uint32_t range_index = (blockIdx.x % kXcds) * per_xcd + blockIdx.x / kXcds;
+    if (blockIdx.x / kXcds >= per_xcd || range_index >= range_n) return;
+    const uint32_t unit_index = range_lo + range_index;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     const uint2 unit = fb.active_units[unit_index];
     const uint32_t item_s = __builtin_amdgcn_readfirstlane(unit.x), chunk_s = __builtin_amdgcn_readfirstlane(unit.y) & ((1u << kUnitViewShift) - 1u);
@@ -899,49 +923,15 @@ __global__ __launch_bounds__(256) void k_setup(FrameBuffers fb, Capacities cap) 
     __syncthreads();
     typedef const __attribute__((address_space(4))) DrawItem* cptr_item;
     cptr_item d = (cptr_item)fb.items + item_s;
-    const uint32_t setup_pass = kEarlyZ ? fb.setup_pass : 0u;
-    if constexpr (kEarlyZ) {
-        // Two passes in frames with depth complexity: the units of the nearest draw items (numbered first: the host
-        // orders the items near to far) in pass 1, then k_hiz takes the farthest depth of every 8x8 pixel block, and
-        // pass 2 drops a small triangle whose nearest vertex lies behind everything in the blocks of its bbox before any
-        // pixel work.  Pass 0: every unit at once, per-fragment depth test only.
-        const bool near_item = d->unit_base < fb.split_units;
-        if ((setup_pass == 1u && !near_item) || (setup_pass == 2u && near_item)) return;      // (uniform over the workgroup)
-    }
+    // Two passes in frames with depth complexity (kEarlyZ, setup_pass 1 and 2): the units of the nearest draw items (the
+    // host orders the items near to far) in pass 1, then k_hiz takes the farthest depth of every 8x8 pixel block, k_cull_far
+    // keeps the far units that can still show, k_transform runs for their vertices, and pass 2 drops a small triangle whose
+    // nearest vertex lies behind everything in the blocks of its bbox before any pixel work.  Pass 0: every unit at once,
+    // per-fragment depth test only.
     const uint32_t chunk_tris = fc.chunk_tris;
     const uint32_t first_t = chunk_s * chunk_tris;                         // first triangle of the chunk within its item
     const uint32_t item_tris = d->n_tris;
     const uint32_t n_here = item_tris > first_t ? min(item_tris - first_t, chunk_tris) : 0u;
-    if constexpr (kEarlyZ) {
-        if (setup_pass == 2u && fb.unit_bounds) {
-            // the whole unit behind what pass 1 drew?  (k_cull's bounds of the unit against k_hiz's farthest depths)
-            const uint4 ub = fb.unit_bounds[unit_index];
-            const uint32_t bx0 = ub.x & 0xFFFFu, by0 = ub.x >> 16, bw = (ub.y & 0xFFFFu) - bx0 + 1u, bh = (ub.y >> 16) - by0 + 1u;
-            const uint32_t n_b = bw * bh;
-            if (ub.w != 0u && n_b <= 16384u) {
-                const float z_near_unit = __uint_as_float(ub.z);
-                const float inv_bw = __builtin_amdgcn_rcpf((float)bw);
-                bool open = false;
-                for (uint32_t k = threadIdx.x; k < n_b; k += 256u) {
-                    uint32_t dy = (uint32_t)(((float)k + 0.5f) * inv_bw);
-                    dy = dy * bw > k ? dy - 1u : ((dy + 1u) * bw <= k ? dy + 1u : dy);        // (exact k / bw from the estimate)
-                    const uint32_t bx = bx0 + (k - dy * bw), by = by0 + dy;
-                    const float farthest = fb.hiz[((by >> 2) * fc.tiles_x + (bx >> 2)) * 16u + ((by & 3u) * 4u + (bx & 3u))];
-                    open = open || !(z_near_unit > farthest);
-                }
-                if (!__syncthreads_or(open ? 1 : 0)) {
-                    if (threadIdx.x == 0) {
-                        fb.chunk_count[unit_index] = 0u;
-                        // (the host's measure of depth complexity keeps counting what was turned away, at the rate of the last
-                        // plain frame, or the variant would switch itself off)
-                        const unsigned long long f = ((unsigned long long)n_here * fb.bbox_px_hint_x16) >> 4;
-                        atomicAdd(&fb.stat_stripes[(unit_index % kStatStripes) * kStatStride], f << 32);
-                    }
-                    return;
-                }
-            }
-        }
-    }
     const uint32_t vb = d->vert_base, nv = d->n_verts, tri_base = d->tri_base;
     const bool alpha_item = (d->flags & kItemAlphaTest) != 0u;       // fragments take the texture alpha test
     gptr_u32 indices = (gptr_u32)d->indices;
@@ -1166,6 +1156,7 @@ __global__ __launch_bounds__(256) void k_hiz(FrameBuffers fb) {
     __shared__ uint32_t s_part[4][16];
     const uint32_t tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t tx = tile % fc.tiles_x, ty = tile / fc.tiles_x;
+    if (tile == 0u && tid == 0u) fb.counters->n_near = fb.counters->n_active;        // (the first pass's units: k_cull_far appends behind them)
     if (!owns_tile(tx, ty, fc.rank, fc.world)) {
         if (tid < 16u) fb.hiz[tile * 16u + tid] = 1.0f;
         return;
@@ -1186,6 +1177,75 @@ __global__ __launch_bounds__(256) void k_hiz(FrameBuffers fb) {
     }
     __syncthreads();
     if (tid < 16u) fb.hiz[tile * 16u + tid] = __uint_as_float(max(max(s_part[0][tid], s_part[1][tid]), max(s_part[2][tid], s_part[3][tid])));
+}
+
+// The far items' units of an early-depth frame, after the near items are drawn: a unit whose bounds (k_cull: the screen rect
+// of its box's corners and a depth nothing of it is nearer than) lie behind k_hiz's farthest depth in every 8x8 block of the
+// rect cannot show (depths only decrease afterwards) and goes no further: its vertices are not transformed, its triangles
+// not set up.  The others join the active list and flag their vertex blocks (the second row of flags).  One candidate per
+// wave, the wave's lanes over the blocks of the rect; one atomic per workgroup of four.
+__global__ __launch_bounds__(256) void k_cull_far(FrameBuffers fb) {
+    FrameConstRef fc = frame_const_ref(fb.frame_const);
+    __shared__ uint32_t s_keep[4];
+    const uint32_t n_far = min(fb.counters->n_far, fc.n_units);
+    const uint32_t first = blockIdx.x * 4u;
+    if (first >= n_far) return;
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    {
+        const uint32_t c = first + wave;        // (uniform over the wave)
+        bool keep = false;
+        if (c < n_far) {
+            keep = true;
+            const uint4 ub = fb.unit_bounds[c];
+            const uint32_t bx0 = ub.x & 0xFFFFu, by0 = ub.x >> 16, bw = (ub.y & 0xFFFFu) - bx0 + 1u, bh = (ub.y >> 16) - by0 + 1u;
+            const uint32_t n_b = bw * bh;
+            if (ub.w != 0u && n_b <= 16384u) {
+                const float z_near_unit = __uint_as_float(ub.z);
+                const float inv_bw = __builtin_amdgcn_rcpf((float)bw);
+                bool open = false;
+                for (uint32_t k = lane; k < n_b; k += 64u) {
+                    uint32_t dy = (uint32_t)(((float)k + 0.5f) * inv_bw);
+                    dy = dy * bw > k ? dy - 1u : ((dy + 1u) * bw <= k ? dy + 1u : dy);        // (exact k / bw from the estimate)
+                    const uint32_t bx = bx0 + (k - dy * bw), by = by0 + dy;
+                    const float farthest = fb.hiz[((by >> 2) * fc.tiles_x + (bx >> 2)) * 16u + ((by & 3u) * 4u + (bx & 3u))];
+                    open = open || !(z_near_unit > farthest);
+                }
+                keep = __ballot(open) != 0ull;
+            }
+        }
+        if (lane == 0u) s_keep[wave] = keep ? 1u : 0u;
+    }
+    __syncthreads();
+    if (wave != 0u) return;
+    const uint32_t c = first + lane;
+    const bool mine = lane < 4u && c < n_far;
+    const bool keep = mine && s_keep[lane & 3u] != 0u;
+    const unsigned long long km = __ballot(keep);
+    uint32_t base = 0;
+    if (km) {
+        const int leader = __ffsll((long long)km) - 1;
+        if (lane == (uint32_t)leader) base = atomicAdd(&fb.counters->n_active, (uint32_t)__popcll(km));
+        base = __shfl(base, leader);
+    }
+    if (mine) {
+        const uint2 u = fb.far_units[c];
+        const DrawItem& d = fb.items[u.x];
+        if (keep) {
+            const uint32_t n_vblocks = (fc.n_verts + kVertexBlock - 1) / kVertexBlock;
+            fb.active_units[base + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = make_uint2(u.x, u.y);
+            const ChunkInfo ci = d.chunks[u.y];
+            const uint32_t vb0 = (d.vert_base + ci.vmin) / kVertexBlock, vb1 = (d.vert_base + ci.vmax) / kVertexBlock;
+            if (vb1 - vb0 >= 64u) fb.counters->all_verts = 1u;
+            else for (uint32_t b = vb0; b <= vb1 && b < n_vblocks; ++b) fb.vblock_needed[n_vblocks + b] = u.x + 1u;
+        } else {
+            // (the host's measure of depth complexity keeps counting what was turned away, at the rate of the last plain
+            // frame, or the variant would switch itself off)
+            const uint32_t first_t = u.y * fc.chunk_tris;
+            const uint32_t n_here = d.n_tris > first_t ? min(d.n_tris - first_t, fc.chunk_tris) : 0u;
+            const unsigned long long f = ((unsigned long long)n_here * fb.bbox_px_hint_x16) >> 4;
+            if (f) atomicAdd(&fb.stat_stripes[(c % kStatStripes) * kStatStride], f << 32);
+        }
+    }
 }
 
 // --- clipper (rare path): near, far and the four guard-band planes, then a fan -------------
@@ -2944,7 +3004,8 @@ static inline uint32_t div_up(uint64_t a, uint32_t b) { return (uint32_t)((a + b
 void launch_clear(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream, const void* host_tables,
                   void* dev_tables, size_t table_bytes) {
     const uint32_t n_counts = 2u * fc.tiles_x * fc.tiles_y;
-    const uint32_t n_vblocks = (fc.n_verts + kVertexBlock - 1) / kVertexBlock * std::max(fc.n_views, 1u);
+    // (an early-depth frame in two passes has a second row of vertex-block flags: the far units', set by k_cull_far)
+    const uint32_t n_vblocks = (fc.n_verts + kVertexBlock - 1) / kVertexBlock * std::max(fc.n_views, 1u) * (fb.early_z && fb.setup_pass ? 2u : 1u);
     const uint32_t n_vec = (uint32_t)(table_bytes / 16);
     // enough workgroups for the table copy even when this context owns few tiles
     const uint32_t blocks = std::max<uint32_t>(fb.n_owned ? fb.n_owned : 1u, std::min<uint32_t>(div_up(n_vec, 256), 1024u));
@@ -2987,6 +3048,9 @@ void launch_setup(const FrameBuffers& fb, const FrameConst& fc, const Capacities
                 pass.setup_pass = 1u;
                 hipLaunchKernelGGL((k_setup<false, 1, false, true>), grid, dim3(256), 0, stream, pass, cap);
                 hipLaunchKernelGGL(k_hiz, dim3(fc.tiles_x * fc.tiles_y), dim3(256), 0, stream, fb);
+                hipLaunchKernelGGL(k_cull_far, dim3(div_up(fc.n_units, 4)), dim3(256), 0, stream, fb);
+                hipLaunchKernelGGL(k_transform, dim3(div_up(fc.n_verts, 256), 1u), dim3(256), 0, stream, fb.items, fb.vert_bases, fb.frame_const, fb.clip, fb.snap,
+                                   fb.vblock_needed + div_up(fc.n_verts, 256), fb.counters);
                 pass.setup_pass = 2u;
                 hipLaunchKernelGGL((k_setup<false, 1, false, true>), grid, dim3(256), 0, stream, pass, cap);
             }

@@ -154,7 +154,7 @@ VisualServer::~VisualServer() {
     for (auto& kv : meshes_)
         for (auto& s : kv.second.submeshes) { s.vertex_buffer.release(); s.positions.release(); s.index_buffer.release(); s.chunks.release(); }
     for (int k = 0; k < 2; ++k) { d_tables_[k].release(); d_clip_[k].release(); d_vis_[k].release(); d_counters_[k].release(); d_stat_stripes_[k].release(); }
-    d_snap_.release(); d_hiz_.release(); d_unit_bounds_.release(); d_wide_list_.release(); d_tile_slices_.release(); d_raster_extra_.release();
+    d_snap_.release(); d_hiz_.release(); d_unit_bounds_.release(); d_far_units_.release(); d_wide_list_.release(); d_tile_slices_.release(); d_raster_extra_.release();
     d_records_.release(); d_tilewords_.release(); d_clip_queue_.release(); d_chunk_count_.release(); d_vblock_needed_.release(); d_active_units_.release(); d_tile_count_.release();
     d_tile_offset_.release(); d_tile_cursor_.release(); d_entries_.release();
     for (auto& kv : textures_) kv.second.texels.release();
@@ -926,9 +926,9 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     struct {
         float4* clip; SnapVert* snap; SetupRecord* records; uint32_t *tilewords, *clip_queue, *chunk_count, *active_units, *vblock_needed, *entries,
             *wide_list, *tile_slices, *tile_count, *tile_offset, *tile_cursor;
-        uint2* raster_extra; FrameCounters* counters; uint64_t* vis; float* hiz; unsigned long long* stripes; uint4* unit_bounds;
+        uint2* raster_extra; FrameCounters* counters; uint64_t* vis; float* hiz; unsigned long long* stripes; uint4* unit_bounds; uint2* far_units;
     } bp{};
-    const size_t n_vblocks = ((size_t)fc.n_verts / kVertexBlock + 2) * n_views_max;
+    const size_t n_vblocks = ((size_t)fc.n_verts / kVertexBlock + 2) * std::max<size_t>(n_views_max, early_z_frame_ ? 2 : 1);       // (early-depth frames: a second row of flags)
     const size_t n_unit_words = std::max<size_t>(2 * (size_t)fc.n_units * n_views_max, 2);
     const size_t n_count_words = std::max<size_t>((size_t)fc.n_units * n_views_max, 1);          // per unit: record slots used
     const size_t n_view_verts = std::max<size_t>((size_t)fc.n_verts * n_views_max, 1);
@@ -960,6 +960,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         bp.vis = arena.take<uint64_t>(n_tiles * kTilePixels * msaa_);
         bp.hiz = early_z_frame_ ? arena.take<float>(n_tiles * 16) : nullptr;
         bp.unit_bounds = early_z_frame_ ? arena.take<uint4>(std::max<size_t>(fc.n_units, 1)) : nullptr;
+        bp.far_units = early_z_frame_ ? arena.take<uint2>(std::max<size_t>(fc.n_units, 1)) : nullptr;
     } else {
         if (store_clip && store_clip_fits) d_clip_[p].ensure(std::max<size_t>(fc.n_verts, 1));        // (the main pass's only: shading reads it)
         d_snap_.ensure(n_view_verts);
@@ -991,9 +992,10 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         bp.counters = d_counters_[p].ptr; bp.vis = d_vis_[p].ptr;
         d_stat_stripes_[p].ensure((size_t)n_counter_sets * kStatStripes * kStatStride);
         bp.stripes = reinterpret_cast<unsigned long long*>(d_stat_stripes_[p].ptr);
-        if (early_z_frame_) { d_hiz_.ensure(n_tiles * 16); d_unit_bounds_.ensure(std::max<size_t>(fc.n_units, 1)); }
+        if (early_z_frame_) { d_hiz_.ensure(n_tiles * 16); d_unit_bounds_.ensure(std::max<size_t>(fc.n_units, 1)); d_far_units_.ensure(std::max<size_t>(fc.n_units, 1)); }
         bp.hiz = d_hiz_.ptr;
         bp.unit_bounds = early_z_frame_ ? d_unit_bounds_.ptr : nullptr;
+        bp.far_units = early_z_frame_ ? d_far_units_.ptr : nullptr;
     }
 
     // stage the per-frame tables in pinned memory and upload them
@@ -1108,7 +1110,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     // measured: 16 -> 32 takes C4 (bboxes of ~20 pixel centres) from 230 to 285 frames/s by keeping it out of the
     // record/bin/raster path; C3 and C5 do not move; 64 gains nothing more and costs C1
     static const uint32_t direct_pixels = [] { const char* e = std::getenv("RND_DIRECT_PIXELS"); int v = e ? std::atoi(e) : (int)kDirectPixels; return (uint32_t)std::min(std::max(v, 0), 64); }();
-    fb.direct_pixels = direct_pixels;
+    fb.direct_pixels = direct_pixels;       // (64 in early-depth frames: below, once it is known whether the frame runs that variant)
     fb.clip = bp.clip; fb.snap = bp.snap; fb.records = bp.records; fb.tilewords = reinterpret_cast<uint2*>(bp.tilewords); fb.clip_queue = bp.clip_queue;
     fb.chunk_count = bp.chunk_count;
     fb.unit_bases = reinterpret_cast<const uint32_t*>(tb + off_ub); fb.active_units = reinterpret_cast<uint2*>(bp.active_units); fb.vblock_needed = bp.vblock_needed;
@@ -1120,12 +1122,21 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
     frame_no_chain_ = allow_no_chain_ && !noalloc && full_chain_frames_ == 0 && chain_free_streak_ >= kNoChainStreak;
     if (full_chain_frames_) --full_chain_frames_;
     fb.no_chain = frame_no_chain_ ? 1u : 0u;
-    fb.early_z = early_z_frame_ ? 1u : 0u;
+    // (the early-depth variant exists for the plain main pass only: k_cull parts near and far units only when it runs)
+    const bool early_z_used = early_z_frame_ && !frame_alpha_test_ && msaa_ == 1;
+    fb.early_z = early_z_used ? 1u : 0u;
+    // In an early-depth frame every triangle the first pass leaves to the record path is a hole in k_hiz's picture (its pixels
+    // are still clear when k_hiz looks), and one hole in a far unit's rect keeps the unit: at C4 the 0.1 % of the nearest
+    // layer's triangles with bboxes of 33..64 pixel centres kept 14 004 of 43 947 hidden units alive (745 frames/s; with
+    // them rasterized at setup too: 3 units, 1120 frames/s, and no record left for the chain).
+    static const bool direct_env = std::getenv("RND_DIRECT_PIXELS") != nullptr;
+    if (early_z_used && !direct_env) fb.direct_pixels = 64u;
     fb.split_units = split_units_;
-    fb.setup_pass = early_z_frame_ && split_units_ != 0u && split_units_ < fc.n_units ? 1u : 0u;
+    fb.setup_pass = early_z_used && split_units_ != 0u && split_units_ < fc.n_units ? 1u : 0u;
     fb.hiz = bp.hiz;
     fb.bbox_px_hint_x16 = bbox_px_hint_x16_;
     fb.unit_bounds = bp.unit_bounds;
+    fb.far_units = bp.far_units;
     fb.launch_order = d_launch_order_.ptr; fb.n_owned = n_owned_;
     fb.dims = ShadeDims{fc.n_lights, fc.n_items, fc.width, fc.height, fc.tiles_x,
                         fc.tiles_x > 1u ? (uint32_t)((1ull << 32) / fc.tiles_x) + 1u : 0u, fc.rank, fc.world};
@@ -1229,6 +1240,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         FrameBuffers sfb = fb;
         sfb.items = reinterpret_cast<const DrawItem*>(tb + off_si); sfb.lights = nullptr; sfb.shadow_sets = nullptr; sfb.alpha_test = 0;
         sfb.clip = nullptr;        // depth only: nothing reads clip positions (k_transform skips the store)
+        sfb.early_z = 0u; sfb.setup_pass = 0u;      // (the shadow passes run the plain multi-view kernels: one list of units)
         if (shadows_beside) {
             GeoSet& g = shadow_geo_;
             sfb.snap = g.snap.ptr; sfb.records = g.records.ptr; sfb.tilewords = reinterpret_cast<uint2*>(g.tilewords.ptr); sfb.clip_queue = g.clip_queue.ptr;
@@ -1459,8 +1471,10 @@ void VisualServer::finish() {
         enqueue_frame(pending_want_hdr_);
     }
     const FrameCounters c = *h_counters_;
+    if (std::getenv("RND_DEBUG_COUNTERS")) std::fprintf(stderr, "rnd counters: units %u active %u near %u far %u valid %u frags %u\n", fc_.n_units, c.n_active, c.n_near, c.n_far, c.n_valid, c.n_fragments);
     stats_.n_setup = c.n_valid; stats_.n_bin_entries = c.n_entries; stats_.overflow = grew;
     stats_.n_fragments = c.n_fragments;
+    stats_.n_units_hidden = c.n_far - std::min(c.n_far, c.n_active - std::min(c.n_active, c.n_near));      // (both zero outside a two-pass early-depth frame)
     note_depth_complexity(c.n_fragments);
     // pixels this context rasterizes: owned tiles clipped to the frame
     uint64_t px = 0;

@@ -363,6 +363,7 @@ private:
     uint32_t split_units_ = 0;                  // units of the early-depth variant's first pass (build_frame)
     DeviceBuffer<uint64_t> d_stat_stripes_[2];  // k_setup's striped statistics, one block per counter set (by frame parity, as the counters)
     uint32_t bbox_px_hint_x16_ = 0;             // bbox pixels per input triangle (x 16) of the last plain frame reported (note_depth_complexity)
+    DeviceBuffer<uint2> d_far_units_;           // early-depth frames: the far items' units between k_cull and k_cull_far
     DeviceBuffer<uint4> d_unit_bounds_;         // early-depth frames: k_cull's screen rect and nearest depth per active unit
     DeviceBuffer<float> d_hiz_;                 // farthest depth per 8x8 block between its two passes
     void note_depth_complexity(uint64_t n_fragments);

@@ -47,9 +47,10 @@ def test_forced_early_depth_matches_plain_and_oracle(monkeypatch, clip):
         gpu.close()
     for a, b in zip(out["0"][:3], out["1"][:3]):
         assert (a == b).all()
-    # the complexity measure: exact in the plain variant; the early-depth variant counts the triangles of the units it
-    # turns away whole at the rate of the last plain frame it saw (none here: forced on from the first frame)
-    assert 0 < out["1"][3] <= out["0"][3]
+    # the complexity measure: exact in the plain variant (bboxes of up to 32 pixel centres); the early-depth variant
+    # rasterizes bboxes of up to 64 at setup and counts the triangles of the units it turns away whole at the rate of the
+    # last plain frame it saw (none here: forced on from the first frame)
+    assert out["1"][3] > 0
 
 
 def test_switches_on_by_itself_and_off_again(monkeypatch):
@@ -133,8 +134,7 @@ def test_units_turned_away_whole_random_occluders(monkeypatch, seed):
     the middle of the depth range (it goes the direct path, so k_hiz holds real depths; it covers only part of the
     screen), and thirty small meshes in front of it, behind it, through it and beside it, some rotated so that their
     boxes are far from axis-aligned.  Whatever is turned away must not have been visible: ids, depth bits and colours
-    against the oracle.  At least one case has units that were turned away and units that were not (the stats say so
-    through n_fragments being below the plain variant's)."""
+    against the oracle.  The odd seeds must have units that were turned away (rnd_frame_stats.n_units_hidden)."""
     from renderer_amd.scenes import SceneDesc, heightfield_mesh
     from renderer_amd.types import Camera, from_translation, from_rotation_x, from_rotation_y
     r = np.random.default_rng(seed)
@@ -166,11 +166,10 @@ def test_units_turned_away_whole_random_occluders(monkeypatch, seed):
         gpu.render()
         st = gpu.frame_stats()
         assert st["early_depth"] == int(mode)
-        counts[mode] = st["n_fragments"]
+        counts[mode] = st["n_units_hidden"]
         assert_parity(gpu, cpu, min_covered=w * h // 8)
         gpu.close()
     cpu.close()
-    print("bbox pixels counted: plain", counts["0"], "early-depth", counts["1"])
-    assert counts["1"] <= counts["0"]
+    assert counts["0"] == 0
     if seed % 2:
-        assert counts["1"] < counts["0"], "no unit was turned away: the case does not test what it is for"
+        assert counts["1"] > 0, "no unit was turned away: the case does not test what it is for"
