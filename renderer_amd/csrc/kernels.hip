@@ -346,6 +346,11 @@ __device__ __forceinline__ SnapVert snap_and_classify(const float4& c, float hal
     return SnapVert{s.x, s.y, s.z, code};
 }
 
+// kBlocks: vertex blocks per workgroup.  1 where most blocks have work.  The second launch of an early-depth frame (the
+// far units k_cull_far kept: at C4 three of 44 k) finds nearly every flag clear, and ~100 k workgroups that read a flag
+// and exit were 30 us; there a workgroup takes 8 consecutive blocks, their flags in one round trip.  (On a sort-first
+// partition, where an eighth of the blocks has work, 8 blocks per workgroup was slower: 15.0 -> 18.7 us.)
+template <uint32_t kBlocks>
 __global__ __launch_bounds__(256) void k_transform(const DrawItem* __restrict__ items,
                                                    const uint32_t* __restrict__ vert_bases, const FrameConst* __restrict__ fcp,
                                                    float4* __restrict__ clip, SnapVert* __restrict__ snap,
@@ -356,42 +361,54 @@ __global__ __launch_bounds__(256) void k_transform(const DrawItem* __restrict__ 
     static_assert(kVertexBlock == 256, "one workgroup per vertex block");
     const uint32_t view = blockIdx.y;                                    // multi-view passes: one grid row per view
     if (!((fc.view_mask >> view) & 1u)) return;
-    // the block's flag (written by k_cull: 1 + a draw item that has vertices here) and the "every block" switch together
-    const uint32_t hint_s = __builtin_amdgcn_readfirstlane(vblock_needed[view * gridDim.x + blockIdx.x]);
-    if (!hint_s && !counters->all_verts) return;      // no surviving work unit reads this block
-    uint32_t gid = blockIdx.x * 256u + threadIdx.x;
-    if (gid >= fc.n_verts) return;
+    const uint32_t n_vblocks = (fc.n_verts + kVertexBlock - 1u) / kVertexBlock;       // (k_cull's row length of the flags)
+    // the blocks' flags (written by k_cull: 1 + a draw item that has vertices here) and the "every block" switch together
+    uint32_t hints[kBlocks];
+#pragma unroll
+    for (uint32_t k = 0; k < kBlocks; ++k) {
+        const uint32_t block = blockIdx.x * kBlocks + k;
+        hints[k] = block < n_vblocks ? __builtin_amdgcn_readfirstlane(vblock_needed[view * n_vblocks + block]) : 0u;
+    }
+    const uint32_t all_verts = counters->all_verts;
     const size_t out_base = (size_t)view * fc.n_verts;
     const int32_t view_dy = (int32_t)(view * fc.view_h) * kSub;          // the view's rows in the stacked target
-    auto transform = [&](const DrawItem& d) {
-        uint32_t v = gid - d.vert_base;
-        float x = ((gptr_f32)d.px)[v], y = ((gptr_f32)d.py)[v], z = ((gptr_f32)d.pz)[v];
-        float4 c = clip_position(d, view_pv(fc, view), x, y, z);
-        // (kept for the shading kernel of frames with few vertices per pixel; null otherwise and in depth-only passes:
-        // see corner_clip)
-        if (clip) clip[gid] = c;
-        const SnapVert sv = snap_and_classify(c, 0.5f * (float)fc.width, 0.5f * (float)fc.view_h);
-        *reinterpret_cast<uint4*>(snap + out_base + gid) = make_uint4((uint32_t)sv.x, (uint32_t)(sv.y + view_dy), __float_as_uint(sv.z), sv.code);
-    };
-    // The usual block lies inside one draw item, the one the flag names: no search (the binary search over the items'
-    // vertex bases is a chain of dependent loads, which is what this kernel's 64-vertex waves cannot hide).
-    unsigned long long pending = __ballot(true);
-    if (hint_s && hint_s <= fc.n_items) {
-        const DrawItem d = load_item_uniform(items, hint_s - 1u);
-        const bool mine = gid - d.vert_base < d.n_verts;         // (unsigned: also false below the item's first vertex)
-        if (mine) transform(d);
-        pending &= ~__ballot(mine);
-    }
-    if (!pending) return;
-    const bool left = (pending >> lane_id()) & 1ull;
-    uint32_t it = left ? find_item(vert_bases, fc.n_items, gid) : 0u;
-    while (pending) {
-        uint32_t cur_s, cur = uniform_pick(it, pending, cur_s);
-        const bool mine = left && it == cur;
-        pending &= ~__ballot(mine);
-        if (mine) {
-            const DrawItem d = load_item_uniform(items, cur_s);
-            transform(d);
+#pragma unroll
+    for (uint32_t k = 0; k < kBlocks; ++k) {
+        const uint32_t hint_s = hints[k];
+        const uint32_t block = blockIdx.x * kBlocks + k;
+        if (block >= n_vblocks || (!hint_s && !all_verts)) continue;      // no surviving work unit reads this block
+        const uint32_t gid = block * 256u + threadIdx.x;
+        if (gid >= fc.n_verts) continue;
+        auto transform = [&](const DrawItem& d) {
+            uint32_t v = gid - d.vert_base;
+            float x = ((gptr_f32)d.px)[v], y = ((gptr_f32)d.py)[v], z = ((gptr_f32)d.pz)[v];
+            float4 c = clip_position(d, view_pv(fc, view), x, y, z);
+            // (kept for the shading kernel of frames with few vertices per pixel; null otherwise and in depth-only passes:
+            // see corner_clip)
+            if (clip) clip[gid] = c;
+            const SnapVert sv = snap_and_classify(c, 0.5f * (float)fc.width, 0.5f * (float)fc.view_h);
+            *reinterpret_cast<uint4*>(snap + out_base + gid) = make_uint4((uint32_t)sv.x, (uint32_t)(sv.y + view_dy), __float_as_uint(sv.z), sv.code);
+        };
+        // The usual block lies inside one draw item, the one the flag names: no search (the binary search over the items'
+        // vertex bases is a chain of dependent loads, which is what this kernel's 64-vertex waves cannot hide).
+        unsigned long long pending = __ballot(true);
+        if (hint_s && hint_s <= fc.n_items) {
+            const DrawItem d = load_item_uniform(items, hint_s - 1u);
+            const bool mine = gid - d.vert_base < d.n_verts;         // (unsigned: also false below the item's first vertex)
+            if (mine) transform(d);
+            pending &= ~__ballot(mine);
+        }
+        if (!pending) continue;
+        const bool left = (pending >> lane_id()) & 1ull;
+        uint32_t it = left ? find_item(vert_bases, fc.n_items, gid) : 0u;
+        while (pending) {
+            uint32_t cur_s, cur = uniform_pick(it, pending, cur_s);
+            const bool mine = left && it == cur;
+            pending &= ~__ballot(mine);
+            if (mine) {
+                const DrawItem d = load_item_uniform(items, cur_s);
+                transform(d);
+            }
         }
     }
 }
@@ -1157,8 +1174,10 @@ __global__ __launch_bounds__(256) void k_hiz(FrameBuffers fb) {
     const uint32_t tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t tx = tile % fc.tiles_x, ty = tile / fc.tiles_x;
     if (tile == 0u && tid == 0u) fb.counters->n_near = fb.counters->n_active;        // (the first pass's units: k_cull_far appends behind them)
+    const uint32_t n_tiles = fc.tiles_x * fc.tiles_y;          // (behind the blocks' 16 per tile: one value per tile, their maximum)
     if (!owns_tile(tx, ty, fc.rank, fc.world)) {
         if (tid < 16u) fb.hiz[tile * 16u + tid] = 1.0f;
+        if (tid == 0u) fb.hiz[n_tiles * 16u + tile] = 1.0f;
         return;
     }
     const unsigned long long* vis = reinterpret_cast<const unsigned long long*>(fb.vis) + (size_t)tile * kTilePixels;
@@ -1176,7 +1195,15 @@ __global__ __launch_bounds__(256) void k_hiz(FrameBuffers fb) {
         for (uint32_t k = 0; k < 4; ++k) s_part[wave][k * 4u + (lane >> 3)] = m[k];
     }
     __syncthreads();
-    if (tid < 16u) fb.hiz[tile * 16u + tid] = __uint_as_float(max(max(s_part[0][tid], s_part[1][tid]), max(s_part[2][tid], s_part[3][tid])));
+    uint32_t far_bits = 0u;
+    if (tid < 16u) {
+        far_bits = max(max(s_part[0][tid], s_part[1][tid]), max(s_part[2][tid], s_part[3][tid]));
+        fb.hiz[tile * 16u + tid] = __uint_as_float(far_bits);
+    }
+    if (wave == 0u) {
+        for (int o : {1, 2, 4, 8}) far_bits = max(far_bits, (uint32_t)__shfl_xor((int)far_bits, o));
+        if (tid == 0u) fb.hiz[n_tiles * 16u + tile] = __uint_as_float(far_bits);
+    }
 }
 
 // The far items' units of an early-depth frame, after the near items are drawn: a unit whose bounds (k_cull: the screen rect
@@ -1201,14 +1228,26 @@ __global__ __launch_bounds__(256) void k_cull_far(FrameBuffers fb) {
             const uint32_t n_b = bw * bh;
             if (ub.w != 0u && n_b <= 16384u) {
                 const float z_near_unit = __uint_as_float(ub.z);
-                const float inv_bw = __builtin_amdgcn_rcpf((float)bw);
+                // whole tiles first (k_hiz's second level: a sixteenth of the loads; at C4 it settles nearly every unit)
+                const uint32_t tx0 = bx0 >> 2, ty0 = by0 >> 2, tw = ((bx0 + bw - 1u) >> 2) - tx0 + 1u, th = ((by0 + bh - 1u) >> 2) - ty0 + 1u;
+                const float* const hiz_tiles = fb.hiz + (size_t)fc.tiles_x * fc.tiles_y * 16u;
+                const float inv_tw = __builtin_amdgcn_rcpf((float)tw);
                 bool open = false;
-                for (uint32_t k = lane; k < n_b; k += 64u) {
-                    uint32_t dy = (uint32_t)(((float)k + 0.5f) * inv_bw);
-                    dy = dy * bw > k ? dy - 1u : ((dy + 1u) * bw <= k ? dy + 1u : dy);        // (exact k / bw from the estimate)
-                    const uint32_t bx = bx0 + (k - dy * bw), by = by0 + dy;
-                    const float farthest = fb.hiz[((by >> 2) * fc.tiles_x + (bx >> 2)) * 16u + ((by & 3u) * 4u + (bx & 3u))];
-                    open = open || !(z_near_unit > farthest);
+                for (uint32_t k = lane; k < tw * th; k += 64u) {
+                    uint32_t dy = (uint32_t)(((float)k + 0.5f) * inv_tw);
+                    dy = dy * tw > k ? dy - 1u : ((dy + 1u) * tw <= k ? dy + 1u : dy);        // (exact k / tw from the estimate)
+                    open = open || !(z_near_unit > hiz_tiles[(ty0 + dy) * fc.tiles_x + tx0 + (k - dy * tw)]);
+                }
+                if (__ballot(open) != 0ull) {
+                    const float inv_bw = __builtin_amdgcn_rcpf((float)bw);
+                    open = false;
+                    for (uint32_t k = lane; k < n_b; k += 64u) {
+                        uint32_t dy = (uint32_t)(((float)k + 0.5f) * inv_bw);
+                        dy = dy * bw > k ? dy - 1u : ((dy + 1u) * bw <= k ? dy + 1u : dy);
+                        const uint32_t bx = bx0 + (k - dy * bw), by = by0 + dy;
+                        const float farthest = fb.hiz[((by >> 2) * fc.tiles_x + (bx >> 2)) * 16u + ((by & 3u) * 4u + (bx & 3u))];
+                        open = open || !(z_near_unit > farthest);
+                    }
                 }
                 keep = __ballot(open) != 0ull;
             }
@@ -3019,7 +3058,7 @@ void launch_cull(const FrameBuffers& fb, const FrameConst& fc, hipStream_t strea
 
 void launch_transform(const FrameBuffers& fb, const FrameConst& fc, hipStream_t stream) {
     if (!fc.n_verts) return;
-    hipLaunchKernelGGL(k_transform, dim3(div_up(fc.n_verts, 256), std::max(fc.n_views, 1u)), dim3(256), 0, stream, fb.items, fb.vert_bases, fb.frame_const, fb.clip, fb.snap,
+    hipLaunchKernelGGL(k_transform<1>, dim3(div_up(fc.n_verts, 256), std::max(fc.n_views, 1u)), dim3(256), 0, stream, fb.items, fb.vert_bases, fb.frame_const, fb.clip, fb.snap,
                        fb.vblock_needed, fb.counters);
 }
 void launch_setup(const FrameBuffers& fb, const FrameConst& fc, const Capacities& cap, hipStream_t stream) {
@@ -3049,7 +3088,7 @@ void launch_setup(const FrameBuffers& fb, const FrameConst& fc, const Capacities
                 hipLaunchKernelGGL((k_setup<false, 1, false, true>), grid, dim3(256), 0, stream, pass, cap);
                 hipLaunchKernelGGL(k_hiz, dim3(fc.tiles_x * fc.tiles_y), dim3(256), 0, stream, fb);
                 hipLaunchKernelGGL(k_cull_far, dim3(div_up(fc.n_units, 4)), dim3(256), 0, stream, fb);
-                hipLaunchKernelGGL(k_transform, dim3(div_up(fc.n_verts, 256), 1u), dim3(256), 0, stream, fb.items, fb.vert_bases, fb.frame_const, fb.clip, fb.snap,
+                hipLaunchKernelGGL(k_transform<8>, dim3(div_up(div_up(fc.n_verts, 256), 8), 1u), dim3(256), 0, stream, fb.items, fb.vert_bases, fb.frame_const, fb.clip, fb.snap,
                                    fb.vblock_needed + div_up(fc.n_verts, 256), fb.counters);
                 pass.setup_pass = 2u;
                 hipLaunchKernelGGL((k_setup<false, 1, false, true>), grid, dim3(256), 0, stream, pass, cap);

@@ -958,7 +958,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         bp.counters = arena.take<FrameCounters>(n_counter_sets);
         bp.stripes = arena.take<unsigned long long>((size_t)n_counter_sets * kStatStripes * kStatStride);
         bp.vis = arena.take<uint64_t>(n_tiles * kTilePixels * msaa_);
-        bp.hiz = early_z_frame_ ? arena.take<float>(n_tiles * 16) : nullptr;
+        bp.hiz = early_z_frame_ ? arena.take<float>(n_tiles * 17) : nullptr;
         bp.unit_bounds = early_z_frame_ ? arena.take<uint4>(std::max<size_t>(fc.n_units, 1)) : nullptr;
         bp.far_units = early_z_frame_ ? arena.take<uint2>(std::max<size_t>(fc.n_units, 1)) : nullptr;
     } else {
@@ -992,7 +992,7 @@ void VisualServer::enqueue_frame(bool want_hdr, uint8_t* noalloc_out, uint64_t n
         bp.counters = d_counters_[p].ptr; bp.vis = d_vis_[p].ptr;
         d_stat_stripes_[p].ensure((size_t)n_counter_sets * kStatStripes * kStatStride);
         bp.stripes = reinterpret_cast<unsigned long long*>(d_stat_stripes_[p].ptr);
-        if (early_z_frame_) { d_hiz_.ensure(n_tiles * 16); d_unit_bounds_.ensure(std::max<size_t>(fc.n_units, 1)); d_far_units_.ensure(std::max<size_t>(fc.n_units, 1)); }
+        if (early_z_frame_) { d_hiz_.ensure(n_tiles * 17); d_unit_bounds_.ensure(std::max<size_t>(fc.n_units, 1)); d_far_units_.ensure(std::max<size_t>(fc.n_units, 1)); }
         bp.hiz = d_hiz_.ptr;
         bp.unit_bounds = early_z_frame_ ? d_unit_bounds_.ptr : nullptr;
         bp.far_units = early_z_frame_ ? d_far_units_.ptr : nullptr;

@@ -7,7 +7,7 @@ FETCH_SIZE reads half of the bytes fetched: MI355X_MICROARCH.md, HBM section; ch
 """
 import ast, hashlib, json, os, sys
 
-KEYS = {"k_clear": "clear", "k_cull": "cull", "k_transform": "transform", "k_setup": "setup", "k_hiz": "setup", "k_clip": "clip",
+KEYS = {"k_clear": "clear", "k_cull": "cull", "k_transform": "transform", "k_setup": "setup", "k_hiz": "setup", "k_cull_far": "setup", "k_transform<8": "setup", "k_clip": "clip",
         "k_scan_tiles": "scan", "k_bin_fill": "bin", "k_raster": "raster", "k_shade": "shade"}
 
 
@@ -23,7 +23,9 @@ def read(path):
         n = int(tail.split()[-1])
         vals = ast.literal_eval("{" + body + "}")
         for k, short in KEYS.items():
-            if "rnd::" + k + "<" in name + "<" or ("rnd::" + k) == name.strip():
+            if k == "k_transform" and "k_transform<8" in name:
+                continue        # (the second launch of an early-depth frame: timed with the setup it belongs to)
+            if "rnd::" + k + "<" in name + "<" or ("rnd::" + k) == name.strip() or (k.endswith("<8") and "rnd::" + k in name):
                 acc = total.setdefault(short, {})
                 for c, v in vals.items():
                     acc[c] = acc.get(c, 0.0) + v * n
