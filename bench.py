@@ -124,14 +124,19 @@ def algorithmic_bytes(stats, n_visible_tris, scene=None):
         src_nv = min(nv, sum(len(sm.vertices) for m in used for sm in scene.meshes[m].submeshes))
         src_nt = min(nt, sum(len(sm.indices) // 3 for m in used for sm in scene.meshes[m].submeshes))
     keeps_clip = 2 * nv <= 3 * p                               # the host's per-frame rule (visual_server.cpp, store_clip)
+    # early-depth frames turn whole work units away before their vertices are transformed or their triangles set up: what
+    # those kernels have to read shrinks with the units kept (units are runs of 1024 triangles in frames above 2 Mi
+    # triangles, of 256 below: FrameConst::chunk_tris)
+    n_units = max(1, -(-nt // (1024 if nt > (2 << 20) else 256)))
+    kept = max(0.0, 1.0 - stats.get("n_units_hidden", 0) / n_units)
     corners = min(3 * n_visible_tris, nv)
     return {
         "clear": 8 * p,                                        # visibility words of the owned tiles
         # SoA positions in, the snapped vertex (x, y, z/w, outcodes) and — in frames that keep them — clip xyzw out
-        "transform": 12 * src_nv + 16 * nv + (16 * nv if keeps_clip else 0),
+        "transform": int(kept * (12 * src_nv + 16 * nv + (16 * nv if keeps_clip else 0))),
         # indices, each snapped vertex once, one 8-byte visibility word per pixel (direct small-triangle
         # path), and for the triangles that go through the bins a 48-byte record + (tile word, bin pos)
-        "setup": 12 * src_nt + 16 * nv + 8 * p + 56 * min(nbin, nrec),
+        "setup": int(kept * (12 * src_nt + 16 * nv)) + 8 * p + 56 * min(nbin, nrec) + (8 * p if stats.get("n_units_hidden", 0) else 0),      # (+ k_hiz reading the visibility words once)
         "bin": 12 * min(nbin, nrec) + 4 * nbin,               # (tile word, bin pos) + tile offset in, bin entries out
         "raster": 52 * nbin + 16 * min(p, 1024 * nbin),       # entries + records per bin entry, visibility tile in and out
         # vis in, rgba8 out, gathers: SURVEY.md 8d's K4 figure — the index triple per visible triangle and, per distinct
