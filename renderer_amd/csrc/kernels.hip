@@ -2366,10 +2366,7 @@ template <bool kShadows, int kSamples, bool kStored>
 // compiler left alone took 101 and with them a fifth wave: C3 + sun shade 0.268 -> 0.241 ms —, plain MSAA 5 (seven
 // spilled dwords at 96 VGPRs against 102 at four waves: C3 MSAA x4 shade 0.72 -> 0.68 ms); the full MSAA variant spills
 // 29 at 4 and keeps its 3)
-#ifndef RND_SHADE_WAVES
-#define RND_SHADE_WAVES 7
-#endif
-__global__ __launch_bounds__(256, kShadows ? (kSamples > 1 ? 1 : 5) : (kSamples > 1 ? 5 : RND_SHADE_WAVES)) void k_shade(FrameBuffers fb, uint32_t n_parts) {
+__global__ __launch_bounds__(256, kShadows ? (kSamples > 1 ? 1 : 5) : (kSamples > 1 ? 5 : 7)) void k_shade(FrameBuffers fb, uint32_t n_parts) {
     FrameConstRef fc = frame_const_ref(fb.frame_const);
     constexpr uint32_t PPT = 2;                                         // fragments per lane in flight: two pixels, or two samples of one
     constexpr uint32_t kPix = kSamples > 1 ? 1u : PPT;                  // pixels per lane
