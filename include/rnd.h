@@ -231,7 +231,13 @@ int rnd_read_overlay_rgba8(rnd_ctx* ctx, uint8_t* dst);
  * the previous frame), the library learns of it without synchronizing (a report in mapped pinned memory, looked at
  * when the next frame is enqueued), grows the stream, and the next rnd_render returns RND_ERR_TRUNCATED once as a
  * notice — that call's frame is enqueued as usual.  rnd_finish (and every read-back) re-runs an overflowed frame
- * until it is complete, so what they return is always a whole frame. */
+ * until it is complete, so what they return is always a whole frame.
+ * The same notice covers one more case: after a run of frames that wrote no setup record, queued nothing for the clipper
+ * and filled no bin, the four kernels of that chain are no longer launched; a frame that turns out to need them is
+ * withheld in the same way (one frame keeps the previous image), the chain comes back for the next 64 frames, and
+ * rnd_finish / the read-backs re-run the withheld frame in full (RND_NO_CHAIN=0 at rnd_create: always launch the chain).
+ * Frames in flight may overlap inside the library (geometry of the next frame, shadow passes on streams of their own);
+ * everything the caller can observe is ordered on the context's stream. */
 int rnd_render(rnd_ctx* ctx);
 int rnd_finish(rnd_ctx* ctx);
 /* The frame of rnd_render for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc,
