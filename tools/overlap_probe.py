@@ -6,8 +6,8 @@ import torch
 import bench
 from renderer_amd import VisualServer, scenes
 
-scene = scenes.c3_grid_10m()
-n = 200
+scene = getattr(scenes, sys.argv[1])() if len(sys.argv) > 1 else scenes.c3_grid_10m()
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 
 
 def run(k):
