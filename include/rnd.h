@@ -289,7 +289,8 @@ int rnd_frame_stats_get(rnd_ctx* ctx, rnd_frame_stats* out);
 /* ---- multi-GPU (no counterpart in the reference, which is single-device;
  *      north_star: sort-first by screen tiles, sort-last depth composite) ------------- */
 /* Sort-first: this context rasterizes/shades only the screen tiles it owns.  Ownership is
- * by full-width stripes of 4 tile rows (128 pixel rows) dealt round-robin: owner = (ty / 4) mod world. */
+ * by full-width stripes of 2 tile rows (64 pixel rows) dealt round-robin from the last rank: owner = world - 1 - (ty / 2) mod world
+ * (when the stripes do not divide evenly the larger shares go to the high ranks; rank 0 also assembles the frame). */
 int rnd_set_tile_partition(rnd_ctx* ctx, uint32_t rank, uint32_t world);
 /* tile edge in pixels (square tiles) and the number of tiles this context owns */
 int rnd_tile_info(const rnd_ctx* ctx, uint32_t* tile_px, uint32_t* n_owned_tiles,

@@ -48,7 +48,7 @@
 namespace orc {
 
 static constexpr uint32_t TILE = 32;          // sort-first tile edge (must match the product)
-static constexpr uint32_t GROUP = 4;          // ownership granularity in tiles
+static constexpr uint32_t GROUP = 2;          // ownership granularity in tile rows (the HIP library's kOwnerGroup)
 static constexpr int SUBPIXEL_BITS = 8;
 static constexpr int SUB = 1 << SUBPIXEL_BITS;  // 256
 static constexpr float GUARD = 16.0f;         // guard band in NDC units
@@ -328,7 +328,7 @@ static constexpr uint32_t QUAD_MESH_ID = 0xFFFFFFFEu;
 static bool owns_tile(const Ctx& c, uint32_t tx, uint32_t ty) {
     if (c.world <= 1) return true;
     (void)tx;
-    return ((ty / GROUP) % c.world) == c.rank;   // full-width stripes of GROUP tile rows
+    return c.world - 1u - (ty / GROUP) % c.world == c.rank;   // full-width stripes of GROUP tile rows, dealt round-robin from the last rank
 }
 static bool owns_pixel(const Ctx& c, uint32_t i, uint32_t j) { return owns_tile(c, i / TILE, j / TILE); }
 

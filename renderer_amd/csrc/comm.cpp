@@ -101,7 +101,7 @@ void VisualServer::gather_tiles() {
     finish();            // a truncated frame is re-run here: its tiles must not leave as they are
     Rccl& r = rccl();
     ncclComm_t c = static_cast<ncclComm_t>(comm_);
-    // every rank's share padded to the largest (rank 0's: stripes are dealt from rank 0)
+    // every rank's share padded to the largest (the first slot's, i.e. the last rank's: stripe_owner)
     uint64_t rows0 = 0;
     for (uint32_t first = 0; first < tiles_y_; first += kOwnerGroup * comm_world_) rows0 += std::min(kOwnerGroup, tiles_y_ - first);
     const size_t stride = (size_t)rows0 * tiles_x_ * kTilePixels * 4;

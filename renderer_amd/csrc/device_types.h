@@ -13,7 +13,10 @@ constexpr uint32_t kWideListTiles = 256;      // a record touching more tiles th
 constexpr uint32_t kWideListCap = 65536;
 constexpr uint32_t kRasterMaxSlices = 8;      // raster workgroups that may share one heavy tile (256 candidates per batch each)
 constexpr uint32_t kRasterExtraCap = 2048;    // work items (tile, slice >= 1) per pass
-constexpr uint32_t kOwnerGroup = 4;            // sort-first ownership: full-width stripes of this many tile rows, dealt round-robin
+constexpr uint32_t kOwnerGroup = 2;            // sort-first ownership: full-width stripes of this many tile rows, dealt round-robin (4K over 8 ranks: 34 stripes, 5 or 4 a rank; with 4 rows a stripe it was 3 or 2: the heaviest rank 0.084 ms a frame against 0.078; single rows: every rank slower)
+// Stripe g belongs to rank world - 1 - g % world: the stripes are dealt from the LAST rank, so that when they do not divide
+// evenly the larger shares go to the high ranks and rank 0, which also assembles the frame, keeps a smaller one.
+__host__ __device__ inline uint32_t stripe_owner(uint32_t group, uint32_t world) { return world - 1u - group % world; }
 constexpr int kSubpixelBits = 8;
 constexpr int kSub = 1 << kSubpixelBits;       // 256 sub-pixel steps per pixel
 constexpr float kGuardBand = 16.0f;            // guard band half-extent in NDC units

@@ -88,7 +88,7 @@ __device__ __forceinline__ uint32_t find_item_wave(const uint32_t* __restrict__ 
 __device__ __forceinline__ bool owns_tile(uint32_t tx, uint32_t ty, uint32_t rank, uint32_t world) {
     if (world <= 1) return true;
     (void)tx;
-    return ((ty / kOwnerGroup) % world) == rank;   // full-width stripes of kOwnerGroup tile rows
+    return stripe_owner(ty / kOwnerGroup, world) == rank;   // full-width stripes of kOwnerGroup tile rows
 }
 
 // 24-bit signed multiply (+ 32-bit add): full-rate instructions that take the low 24 bits of their operands as they
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void k_cull(FrameBuffers fb) {
                         const uint32_t ty1 = min((uint32_t)fminf(sy1, (float)fc.height), fc.height - 1u) / kTile;
                         const uint32_t g0 = ty0 / kOwnerGroup, g1 = ty1 / kOwnerGroup;
                         bool owned = g1 - g0 + 1u >= fc.world;
-                        for (uint32_t g = g0; !owned && g <= g1; ++g) owned = (g % fc.world) == fc.rank;
+                        for (uint32_t g = g0; !owned && g <= g1; ++g) owned = stripe_owner(g, fc.world) == fc.rank;
                         active = owned;
                     }
                 }
@@ -2393,7 +2393,8 @@ __global__ __launch_bounds__(256, kShadows ? (kSamples > 1 ? 1 : 5) : (kSamples 
         if (fb.dims.world > 1u) {
             // the idx-th owned tile of a stripe partition: full-width stripes of kOwnerGroup tile rows, dealt round-robin
             const uint32_t row = fb.dims.tiles_x_magic ? __umulhi(idx, fb.dims.tiles_x_magic) : idx, tx = idx - row * fb.dims.tiles_x;
-            tile = (((row / kOwnerGroup) * fb.dims.world + fb.dims.rank) * kOwnerGroup + row % kOwnerGroup) * fb.dims.tiles_x + tx;
+            // (rank r holds slot world - 1 - r of every round: stripe_owner)
+            tile = (((row / kOwnerGroup) * fb.dims.world + (fb.dims.world - 1u - fb.dims.rank)) * kOwnerGroup + row % kOwnerGroup) * fb.dims.tiles_x + tx;
         }
         return p < n_parts && j < q + (xcd < r ? 1u : 0u);       // (the last tiles of an XCD's run may not exist)
     };
@@ -2830,12 +2831,12 @@ __global__ void k_detile(const uint32_t* __restrict__ tiles_rgba8, const uint32_
 
 // All ranks' tile-major buffers (rank r at gathered + r * stride_words) into the row-major frame in one
 // launch, one workgroup per tile of the frame.  With full-width stripes of kOwnerGroup tile rows dealt
-// round-robin, tile (tx, ty) belongs to rank (ty / kOwnerGroup) % world and is number
+// round-robin from the last rank, tile (tx, ty) belongs to rank stripe_owner(ty / kOwnerGroup, world) and is number
 // ((ty / kOwnerGroup / world) * kOwnerGroup + ty % kOwnerGroup) * tiles_x + tx of that rank's ascending list.
 __global__ void k_detile_gathered(const uint32_t* __restrict__ gathered, uint64_t stride_words, uint32_t world,
                                   FrameConst fc, uint32_t* frame) {
     const uint32_t tile = blockIdx.x, tx = tile % fc.tiles_x, ty = tile / fc.tiles_x;
-    const uint32_t group = ty / kOwnerGroup, owner = group % world;
+    const uint32_t group = ty / kOwnerGroup, owner = stripe_owner(group, world);
     const uint32_t compact = ((group / world) * kOwnerGroup + ty % kOwnerGroup) * fc.tiles_x + tx;
     const uint32_t* src = gathered + (size_t)owner * stride_words + (size_t)compact * kTilePixels;
     const uint32_t tile_x0 = tx * kTile, tile_y0 = ty * kTile;

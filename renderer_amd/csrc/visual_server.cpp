@@ -227,7 +227,7 @@ std::vector<uint32_t> VisualServer::owned_tiles(uint32_t rank, uint32_t world) c
     std::vector<uint32_t> out;
     for (uint32_t ty = 0; ty < tiles_y_; ++ty)
         for (uint32_t tx = 0; tx < tiles_x_; ++tx)
-            if (world <= 1 || ((ty / kOwnerGroup) % world) == rank) out.push_back(ty * tiles_x_ + tx);
+            if (world <= 1 || stripe_owner(ty / kOwnerGroup, world) == rank) out.push_back(ty * tiles_x_ + tx);
     return out;
 }
 
@@ -1618,7 +1618,7 @@ void VisualServer::detile(uint32_t src_rank, uint32_t world, const void* dev_til
 
 void VisualServer::detile_gathered(uint32_t world, const void* dev_gathered, uint64_t stride_bytes) {
     if (!dev_gathered || world == 0 || stride_bytes % 4) throw Error(RND_ERR_INVALID, "bad detile arguments");
-    // the largest share is rank 0's (stripes are dealt from rank 0)
+    // the largest share is the first slot's (the last rank's: stripe_owner)
     uint64_t rows0 = 0;
     for (uint32_t first = 0; first < tiles_y_; first += kOwnerGroup * world) rows0 += std::min(kOwnerGroup, tiles_y_ - first);
     if (stride_bytes < rows0 * tiles_x_ * kTilePixels * 4) throw Error(RND_ERR_INVALID, "gathered stride smaller than the largest rank's tiles");

@@ -15,12 +15,13 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-OWNER_GROUP = 4     # tile rows per ownership stripe (csrc/device_types.h kOwnerGroup)
+OWNER_GROUP = 2     # tile rows per ownership stripe (csrc/device_types.h kOwnerGroup)
 
 
 def owned_tiles(rank, world, tiles_x, tiles_y):
-    """Ascending tile indices owned by `rank` (must match rnd::VisualServer::owned_tiles)."""
-    return [ty * tiles_x + tx for ty in range(tiles_y) if world <= 1 or (ty // OWNER_GROUP) % world == rank
+    """Ascending tile indices owned by `rank` (must match rnd::VisualServer::owned_tiles): stripes of OWNER_GROUP tile rows dealt
+    round-robin from the LAST rank, so that rank 0, which assembles the frame, never holds the larger share."""
+    return [ty * tiles_x + tx for ty in range(tiles_y) if world <= 1 or world - 1 - (ty // OWNER_GROUP) % world == rank
             for tx in range(tiles_x)]
 
 

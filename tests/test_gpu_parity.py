@@ -478,7 +478,8 @@ def test_overlay_on_a_tile_partition():
         vs.render()
         img = vs.read_color_rgba8()
         ov = vs.read_overlay_rgba8()
-        ty = (np.arange(s.height) // 32 // 4) % world == rank
+        from renderer_amd.sort_first import OWNER_GROUP
+        ty = world - 1 - (np.arange(s.height) // 32 // OWNER_GROUP) % world == rank
         got[ty] = img[ty]
         got_ov[ty] = ov[ty]
         assert not ov[~ty].any()
