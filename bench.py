@@ -207,6 +207,9 @@ def main():
         rendered = [torch.cuda.Event() for _ in range(2)]
         collected = [torch.cuda.Event() for _ in range(2)]
         detiled = [torch.cuda.Event() for _ in range(2)]     # rank 0: the gather list of this buffer has been read
+        tile_args = [(g.tiles.data_ptr(), g.tiles.numel()) for g in gathers]
+        detile_args = [(C.c_void_p(g.gathered_all.data_ptr()), g.gathered_all.stride(0)) for g in gathers] if rank == 0 else None
+        torch.cuda.set_stream(comm)                          # the exchange stream is torch's current stream from here on
     if args.as_rank and world == 1:
         r, w = (int(x) for x in args.as_rank.split("/"))
         vs.set_tile_partition(r, w)
@@ -253,26 +256,26 @@ def main():
 
     def step():
         if world == 1:
-            with torch.cuda.stream(stream):
-                driver.frame()
+            driver.frame()          # (the library launches on the stream it was given: no torch stream context needed)
             return
         if sort_last:
             return step_sort_last()
         b = frame_no[0] & 1
         frame_no[0] += 1
         g = gathers[b]
-        with torch.cuda.stream(stream):
-            stream.wait_event(collected[b])           # the gather that last read this buffer is done
-            vs.set_tiles_output(g.tiles.data_ptr(), g.tiles.numel())
-            driver.frame()
-            rendered[b].record(stream)
+        # (no torch stream contexts in the loop: the library launches on the stream it was given, events take their stream
+        # as an argument, and torch's current stream IS the exchange stream for the whole run — a context manager costs
+        # the host several microseconds, and at eight ranks a frame is ~70 us of GPU time)
+        stream.wait_event(collected[b])               # the gather that last read this buffer is done
+        vs.set_tiles_output(*tile_args[b])
+        driver.frame()
+        rendered[b].record(stream)
         if rank == 0:
             detile_pending()                          # frame i-1, queued behind frame i's kernels
-        with torch.cuda.stream(comm):
-            comm.wait_event(rendered[b])
-            comm.wait_event(detiled[b])
-            gathered = g.gather()
-            collected[b].record(comm)
+        comm.wait_event(rendered[b])
+        comm.wait_event(detiled[b])
+        gathered = g.gather()                         # (on torch's current stream: comm)
+        collected[b].record(comm)
         if rank == 0:
             pending.append((b, gathered))
 
@@ -281,13 +284,11 @@ def main():
     def detile_pending():
         while pending:
             b, gathered = pending.pop(0)
-            with torch.cuda.stream(stream):
-                stream.wait_event(collected[b])
-                ga = gathers[b].gathered_all
-                rc = vs.api.detile_gathered(vs._ctx, world, C.c_void_p(ga.data_ptr()), ga.stride(0))
-                if rc:
-                    raise RuntimeError("detile failed: " + (vs.api.last_error(vs._ctx) or b"").decode())
-                detiled[b].record(stream)
+            stream.wait_event(collected[b])
+            rc = vs.api.detile_gathered(vs._ctx, world, *detile_args[b])
+            if rc:
+                raise RuntimeError("detile failed: " + (vs.api.last_error(vs._ctx) or b"").decode())
+            detiled[b].record(stream)
 
     def fence():
         if sort_last:
